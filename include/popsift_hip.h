@@ -1,0 +1,173 @@
+/*
+ * popsift_hip.h -- thin C ABI between the C++ host layer (libpopsift) and the
+ * HIP/CDNA4 SIFT extraction kernels (libpopsift_hip.so).
+ *
+ * The reference (10183308/popsift) has no FFI: its boundary is the C++ class API
+ * (popsift.h:40-167).  BASELINE.json's north_star asks for "the C++ host ...
+ * calling HIP through a thin C-ABI"; SURVEY.md section 8(b) lists the entry points.
+ * Each function below cites the reference member function(s) it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative
+ * popsift_hip_status on failure; no C++ types, no exceptions, no torch types.
+ * A context is owned by one host thread at a time; distinct contexts (also on
+ * the same device) are fully independent (the reference's process-global
+ * counters, sift_pyramid.cu:38-49, do not exist here).
+ */
+#ifndef POPSIFT_HIP_H
+#define POPSIFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POPSIFT_HIP_MAX_OCTAVES 20 /* sift_conf.h:13 MAX_OCTAVES */
+#define POPSIFT_HIP_MAX_LEVELS 12  /* sift_constants.h:35 GAUSS_LEVELS */
+#define POPSIFT_HIP_GAUSS_ALIGN 32 /* sift_constants.h:34 GAUSS_ALIGN */
+#define POPSIFT_HIP_ORI_MAX 4      /* sift_constants.h:51 ORIENTATION_MAX_COUNT */
+
+typedef enum popsift_hip_status {
+    POPSIFT_HIP_OK = 0,
+    POPSIFT_HIP_ERR_INVALID = -1,     /* bad argument / unsupported mode        */
+    POPSIFT_HIP_ERR_DEVICE = -2,      /* a HIP runtime call failed              */
+    POPSIFT_HIP_ERR_NO_DEVICE = -3,   /* no usable GPU                          */
+    POPSIFT_HIP_ERR_OOM = -4,         /* host or device allocation failed       */
+    POPSIFT_HIP_ERR_STATE = -5,       /* call sequence error (e.g. fetch first) */
+    POPSIFT_HIP_ERR_TOO_SMALL = -6    /* caller buffer too small                */
+} popsift_hip_status;
+
+/* enum values follow the declaration order in sift_conf.h:32-72 */
+enum { POPSIFT_HIP_SIFT_POPSIFT = 0, POPSIFT_HIP_SIFT_OPENCV = 1, POPSIFT_HIP_SIFT_VLFEAT = 2 };
+enum { POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE = 0, POPSIFT_HIP_GAUSS_VLFEAT_RELATIVE = 1,
+       POPSIFT_HIP_GAUSS_VLFEAT_RELATIVE_ALL = 2, POPSIFT_HIP_GAUSS_OPENCV_COMPUTE = 3,
+       POPSIFT_HIP_GAUSS_FIXED9 = 4, POPSIFT_HIP_GAUSS_FIXED15 = 5 };
+enum { POPSIFT_HIP_DESC_LOOP = 0, POPSIFT_HIP_DESC_ILOOP = 1, POPSIFT_HIP_DESC_GRID = 2,
+       POPSIFT_HIP_DESC_IGRID = 3, POPSIFT_HIP_DESC_NOTILE = 4 };
+enum { POPSIFT_HIP_NORM_ROOTSIFT = 0, POPSIFT_HIP_NORM_CLASSIC = 1 };
+
+/* Flattened popsift::Config (sift_conf.h:28-310, defaults sift_conf.cu:17-39). */
+typedef struct popsift_hip_params {
+    int32_t octaves;             /* -1 = auto (popsift.cpp:107-111)            */
+    int32_t levels;              /* DoG search levels, clamped to >= 2         */
+    float   sigma;               /* 1.6                                        */
+    float   edge_limit;          /* 10                                         */
+    float   threshold;           /* Config::_threshold, 0.04                   */
+    float   upscale_factor;      /* +1 => input stretched by 2                 */
+    int32_t sift_mode;           /* POPSIFT_HIP_SIFT_*                         */
+    int32_t gauss_mode;          /* POPSIFT_HIP_GAUSS_*                        */
+    int32_t desc_mode;           /* POPSIFT_HIP_DESC_*                         */
+    int32_t norm_mode;           /* POPSIFT_HIP_NORM_*                         */
+    int32_t norm_multi;          /* descriptor *= 2^norm_multi                 */
+    int32_t max_extrema;         /* per octave, 100000                         */
+    int32_t assume_initial_blur; /* 1                                          */
+    float   initial_blur;        /* 0.5                                        */
+    int32_t filter_grid_size;    /* 2 (only feeds InitialExtremum::cell)       */
+    int32_t reserved[5];
+} popsift_hip_params;
+
+/* POD mirror of popsift::Feature (features.h:22-34): the four Descriptor*
+ * become indices into the descriptor array (-1 = unused slot). */
+typedef struct popsift_hip_feature {
+    int32_t debug_octave;
+    float   xpos;
+    float   ypos;
+    float   sigma;
+    int32_t num_ori;
+    float   orientation[POPSIFT_HIP_ORI_MAX];
+    int32_t desc_idx[POPSIFT_HIP_ORI_MAX];
+} popsift_hip_feature;
+
+/* Pre-orientation extremum (sift_extremum.h:24-33 InitialExtremum), for stage tests. */
+typedef struct popsift_hip_extremum {
+    float   xpos;
+    float   ypos;
+    int32_t lpos;
+    float   sigma;
+    int32_t octave;
+    int32_t cell;
+} popsift_hip_extremum;
+
+/* Per-image timing / counter report (device side, HIP events). */
+typedef struct popsift_hip_report {
+    int32_t num_octaves;
+    int32_t base_w, base_h;
+    int32_t ext_ct[POPSIFT_HIP_MAX_OCTAVES];
+    int32_t ori_ct[POPSIFT_HIP_MAX_OCTAVES];
+    int32_t ext_total, ori_total;
+    float   ms_device;      /* first kernel -> last kernel of the image          */
+    float   ms_blur;        /* sum of blur-level kernel durations (profile mode) */
+    int32_t blur_launches;  /* number of blur-level launches (profile mode)      */
+    double  blur_alg_bytes; /* algorithmic bytes of those launches               */
+    double  pyramid_pixels; /* sum over octaves of w*h                           */
+} popsift_hip_report;
+
+typedef struct popsift_hip_ctx popsift_hip_ctx;
+
+/* Fills p with the defaults of popsift::Config::Config() (sift_conf.cu:17-39). */
+void popsift_hip_default_params(popsift_hip_params* p);
+
+/* Library / build identification string (static storage). */
+const char* popsift_hip_version(void);
+const char* popsift_hip_strerror(int status);
+/* Message of the last failure on this context (static per-context storage). */
+const char* popsift_hip_last_error(const popsift_hip_ctx* ctx);
+
+/* Replaces common/device_prop.cu:23-47 (device enumeration). */
+int popsift_hip_device_count(int* count);
+
+/* Replaces PopSift::configure (popsift.cpp:63-87: init_filter + init_constants)
+ * and Pyramid::Pyramid (sift_pyramid.cu:108-165); buffers are sized lazily on
+ * the first image and only grow (contrast sift_octave.cu:55-89). */
+int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_ctx** out);
+/* Replaces PopSift::uninit / Pyramid::~Pyramid (popsift.cpp:122-137). */
+int popsift_hip_ctx_destroy(popsift_hip_ctx* ctx);
+
+/* Gauss tables as uploaded to the device (gauss_filter.cu:127-257), for KATs:
+ * filter[(levels+3) * 32], span[levels+3], sigma[levels+3]. */
+int popsift_hip_get_gauss_table(const popsift_hip_ctx* ctx, float* filter, int* span, float* sigma,
+                                int* n_levels);
+
+/* Replaces Image::load + Pyramid::step1 + step2 (s_image.cu:71-79,
+ * sift_pyramid.cu:226-239): upload one host image and enqueue the whole
+ * extraction asynchronously on the context's stream.  pitch in elements.
+ * u8 values are 0..255, f32 values are [0,1) (popsift.h:108-116). */
+int popsift_hip_submit_u8(popsift_hip_ctx* ctx, const uint8_t* img, int w, int h, int pitch);
+int popsift_hip_submit_f32(popsift_hip_ctx* ctx, const float* img, int w, int h, int pitch);
+/* Same, image already resident in this device's memory (bench "inputs in HBM"). */
+int popsift_hip_submit_dev_u8(popsift_hip_ctx* ctx, const void* d_img, int w, int h, int pitch);
+int popsift_hip_submit_dev_f32(popsift_hip_ctx* ctx, const void* d_img, int w, int h, int pitch);
+
+/* Replaces the counter read-back of Pyramid::get_descriptors
+ * (sift_pyramid.cu:281-294): blocks until the submitted image is finished and
+ * returns the feature / descriptor counts. */
+int popsift_hip_wait(popsift_hip_ctx* ctx, int* n_features, int* n_descriptors);
+/* Replaces prep_features + the two D2H copies (sift_pyramid.cu:249-321).
+ * feats: n_features entries; desc: n_descriptors * 128 floats. */
+int popsift_hip_fetch(popsift_hip_ctx* ctx, popsift_hip_feature* feats, size_t feats_cap,
+                      float* desc, size_t desc_cap);
+/* Device-resident results (FeaturesDev analogue, features.h:98-118): pointers
+ * stay valid until the next submit on this context. */
+int popsift_hip_results_dev(popsift_hip_ctx* ctx, const void** d_feats, const void** d_desc);
+
+int popsift_hip_get_report(const popsift_hip_ctx* ctx, popsift_hip_report* rep);
+/* profile != 0: bracket every blur-level launch with HIP events (serialises the
+ * octave streams; used by bench.py for the roofline object only). */
+int popsift_hip_set_profile(popsift_hip_ctx* ctx, int profile);
+
+/* Debug / parity hooks (replace Octave::download_and_save_array,
+ * sift_octave.cu:110-187).  kind: 0 = Gaussian plane, 1 = DoG plane. */
+int popsift_hip_octave_dims(const popsift_hip_ctx* ctx, int octave, int* w, int* h);
+int popsift_hip_download_plane(popsift_hip_ctx* ctx, int octave, int kind, int level, float* out);
+/* Overwrite a plane (stage isolation in tests), then re-run later stages. */
+int popsift_hip_upload_plane(popsift_hip_ctx* ctx, int octave, int kind, int level, const float* in);
+/* Initial extrema of the last image, all octaves, in device compaction order. */
+int popsift_hip_download_extrema(popsift_hip_ctx* ctx, popsift_hip_extremum* out, size_t cap, int* n);
+/* Re-run extrema + orientation + descriptors on the planes currently in memory. */
+int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPSIFT_HIP_H */

@@ -1,0 +1,238 @@
+"""ctypes binding of the C ABI in include/popsift_hip.h (libpopsift_hip.so).
+
+This is the only way Python reaches the extraction path: there is no CPU
+fallback.  If the HIP library is missing or fails to load, importing the
+symbols raises -- loudly -- instead of silently computing somewhere else.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpopsift_hip.so")
+
+MAX_OCTAVES = 20
+ORI_MAX = 4
+
+OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_NO_DEVICE, ERR_OOM, ERR_STATE, ERR_TOO_SMALL = -1, -2, -3, -4, -5, -6
+
+SIFT_POPSIFT, SIFT_OPENCV, SIFT_VLFEAT = 0, 1, 2
+GAUSS_VLFEAT_COMPUTE, GAUSS_VLFEAT_RELATIVE, GAUSS_VLFEAT_RELATIVE_ALL = 0, 1, 2
+GAUSS_OPENCV_COMPUTE, GAUSS_FIXED9, GAUSS_FIXED15 = 3, 4, 5
+DESC_LOOP, DESC_ILOOP, DESC_GRID, DESC_IGRID, DESC_NOTILE = 0, 1, 2, 3, 4
+NORM_ROOTSIFT, NORM_CLASSIC = 0, 1
+
+
+class Params(C.Structure):
+    """popsift_hip_params"""
+    _fields_ = [
+        ("octaves", C.c_int32), ("levels", C.c_int32), ("sigma", C.c_float),
+        ("edge_limit", C.c_float), ("threshold", C.c_float), ("upscale_factor", C.c_float),
+        ("sift_mode", C.c_int32), ("gauss_mode", C.c_int32), ("desc_mode", C.c_int32),
+        ("norm_mode", C.c_int32), ("norm_multi", C.c_int32), ("max_extrema", C.c_int32),
+        ("assume_initial_blur", C.c_int32), ("initial_blur", C.c_float),
+        ("filter_grid_size", C.c_int32), ("reserved", C.c_int32 * 5),
+    ]
+
+
+class Report(C.Structure):
+    """popsift_hip_report"""
+    _fields_ = [
+        ("num_octaves", C.c_int32), ("base_w", C.c_int32), ("base_h", C.c_int32),
+        ("ext_ct", C.c_int32 * MAX_OCTAVES), ("ori_ct", C.c_int32 * MAX_OCTAVES),
+        ("ext_total", C.c_int32), ("ori_total", C.c_int32),
+        ("ms_device", C.c_float), ("ms_blur", C.c_float), ("blur_launches", C.c_int32),
+        ("blur_alg_bytes", C.c_double), ("pyramid_pixels", C.c_double),
+    ]
+
+
+FEATURE_DTYPE = np.dtype([
+    ("debug_octave", np.int32), ("xpos", np.float32), ("ypos", np.float32),
+    ("sigma", np.float32), ("num_ori", np.int32),
+    ("orientation", np.float32, (ORI_MAX,)), ("desc_idx", np.int32, (ORI_MAX,)),
+])
+EXTREMUM_DTYPE = np.dtype([
+    ("xpos", np.float32), ("ypos", np.float32), ("lpos", np.int32),
+    ("sigma", np.float32), ("octave", np.int32), ("cell", np.int32),
+])
+
+# every symbol include/popsift_hip.h declares: (name, restype, argtypes)
+_vp, _ip = C.c_void_p, C.POINTER(C.c_int)
+SYMBOLS = [
+    ("popsift_hip_default_params", None, [C.POINTER(Params)]),
+    ("popsift_hip_version", C.c_char_p, []),
+    ("popsift_hip_strerror", C.c_char_p, [C.c_int]),
+    ("popsift_hip_last_error", C.c_char_p, [_vp]),
+    ("popsift_hip_device_count", C.c_int, [_ip]),
+    ("popsift_hip_ctx_create", C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(_vp)]),
+    ("popsift_hip_ctx_destroy", C.c_int, [_vp]),
+    ("popsift_hip_get_gauss_table", C.c_int, [_vp, _vp, _vp, _vp, _ip]),
+    ("popsift_hip_submit_u8", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_submit_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_submit_dev_u8", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_submit_dev_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_wait", C.c_int, [_vp, _ip, _ip]),
+    ("popsift_hip_fetch", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    ("popsift_hip_results_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("popsift_hip_get_report", C.c_int, [_vp, C.POINTER(Report)]),
+    ("popsift_hip_set_profile", C.c_int, [_vp, C.c_int]),
+    ("popsift_hip_octave_dims", C.c_int, [_vp, C.c_int, _ip, _ip]),
+    ("popsift_hip_download_plane", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    ("popsift_hip_upload_plane", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    ("popsift_hip_download_extrema", C.c_int, [_vp, _vp, C.c_size_t, _ip]),
+    ("popsift_hip_rerun_keypoint_stages", C.c_int, [_vp]),
+]
+
+_lib = None
+
+
+class PopsiftHipError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %d (%s)" % (where, status, lib().popsift_hip_strerror(status).decode())
+        if detail:
+            msg += ": " + detail
+        super().__init__(msg)
+
+
+def lib():
+    """Load libpopsift_hip.so; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def default_params(**kw):
+    p = Params()
+    lib().popsift_hip_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().popsift_hip_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+class Context:
+    """One extraction context (popsift_hip_ctx) on one GPU."""
+
+    def __init__(self, params=None, device=0):
+        self._h = None
+        self.params = params if params is not None else default_params()
+        h = _vp()
+        rc = lib().popsift_hip_ctx_create(device, C.byref(self.params), C.byref(h))
+        if rc != OK:
+            raise PopsiftHipError(rc, "popsift_hip_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().popsift_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc != OK:
+            raise PopsiftHipError(rc, where, lib().popsift_hip_last_error(self._h).decode())
+
+    def gauss_table(self):
+        n = C.c_int()
+        self._chk(lib().popsift_hip_get_gauss_table(self._h, None, None, None, C.byref(n)), "get_gauss_table")
+        f = np.zeros((n.value, 32), np.float32)
+        s = np.zeros(n.value, np.int32)
+        g = np.zeros(n.value, np.float32)
+        self._chk(lib().popsift_hip_get_gauss_table(self._h, f.ctypes.data, s.ctypes.data, g.ctypes.data,
+                                                    C.byref(n)), "get_gauss_table")
+        return f, s, g
+
+    def submit(self, img):
+        img = np.ascontiguousarray(img)
+        if img.ndim != 2:
+            raise ValueError("grayscale (H, W) image expected")
+        h, w = img.shape
+        if img.dtype == np.uint8:
+            rc = lib().popsift_hip_submit_u8(self._h, img.ctypes.data, w, h, w)
+        elif img.dtype == np.float32:
+            rc = lib().popsift_hip_submit_f32(self._h, img.ctypes.data, w, h, w)
+        else:
+            raise TypeError("uint8 or float32 image expected, got %s" % img.dtype)
+        self._chk(rc, "popsift_hip_submit")
+        return self
+
+    def submit_dev(self, ptr, w, h, pitch, is_f32=False):
+        fn = lib().popsift_hip_submit_dev_f32 if is_f32 else lib().popsift_hip_submit_dev_u8
+        self._chk(fn(self._h, ptr, w, h, pitch), "popsift_hip_submit_dev")
+        return self
+
+    def wait(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(lib().popsift_hip_wait(self._h, C.byref(a), C.byref(b)), "popsift_hip_wait")
+        return a.value, b.value
+
+    def fetch(self):
+        nf, nd = self.wait()
+        feats = np.zeros(nf, FEATURE_DTYPE)
+        desc = np.zeros((nd, 128), np.float32)
+        self._chk(lib().popsift_hip_fetch(self._h, feats.ctypes.data, nf, desc.ctypes.data, nd * 128),
+                  "popsift_hip_fetch")
+        return feats, desc
+
+    def report(self):
+        r = Report()
+        self._chk(lib().popsift_hip_get_report(self._h, C.byref(r)), "popsift_hip_get_report")
+        return r
+
+    def set_profile(self, on):
+        self._chk(lib().popsift_hip_set_profile(self._h, 1 if on else 0), "popsift_hip_set_profile")
+
+    def octave_dims(self, o):
+        w, h = C.c_int(), C.c_int()
+        self._chk(lib().popsift_hip_octave_dims(self._h, o, C.byref(w), C.byref(h)), "popsift_hip_octave_dims")
+        return w.value, h.value
+
+    def plane(self, octave, kind, level):
+        w, h = self.octave_dims(octave)
+        out = np.zeros((h, w), np.float32)
+        self._chk(lib().popsift_hip_download_plane(self._h, octave, kind, level, out.ctypes.data), "download_plane")
+        return out
+
+    def upload_plane(self, octave, kind, level, arr):
+        w, h = self.octave_dims(octave)
+        arr = np.ascontiguousarray(arr, np.float32)
+        assert arr.shape == (h, w)
+        self._chk(lib().popsift_hip_upload_plane(self._h, octave, kind, level, arr.ctypes.data), "upload_plane")
+
+    def extrema(self):
+        n = C.c_int()
+        self._chk(lib().popsift_hip_download_extrema(self._h, None, 0, C.byref(n)), "download_extrema")
+        out = np.zeros(n.value, EXTREMUM_DTYPE)
+        self._chk(lib().popsift_hip_download_extrema(self._h, out.ctypes.data, n.value, C.byref(n)),
+                  "download_extrema")
+        return out
+
+    def rerun_keypoint_stages(self):
+        self._chk(lib().popsift_hip_rerun_keypoint_stages(self._h), "rerun_keypoint_stages")
+        return self

@@ -1,0 +1,703 @@
+/*
+ * ctx.hip -- C-ABI implementation of libpopsift_hip (include/popsift_hip.h):
+ * per-GPU extraction context, Gauss / constant tables, HBM arena and the
+ * per-image launch sequence.
+ *
+ * Replaces the host side of the reference's L3 layer:
+ *   init_filter / init_constants      gauss_filter.cu:127-257, sift_constants.cu:22-53
+ *   Pyramid::Pyramid / Octave::alloc  sift_pyramid.cu:108-165, sift_octave.cu:33-53
+ *   Pyramid::step1 / build_pyramid    sift_pyramid.cu:226-230, s_pyramid_build.cu:460-596
+ *   Pyramid::step2                    sift_pyramid.cu:232-239
+ *   Pyramid::get_descriptors          sift_pyramid.cu:281-321
+ * with no process-global state: every context owns its stream, arena and
+ * counters, so any number of contexts can run per process / per GPU.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+#include "sift_types.h"
+
+using namespace popsift_hip;
+
+namespace {
+
+constexpr int PITCH_ALIGN = 64; /* floats: rows start on 256 B */
+
+struct HostTables {
+    float filter[POPSIFT_HIP_MAX_LEVELS * PS_GA];
+    int   span[POPSIFT_HIP_MAX_LEVELS];
+    float sigma[POPSIFT_HIP_MAX_LEVELS];
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    double     bytes;
+};
+
+}  // namespace
+
+struct popsift_hip_ctx {
+    int                device = 0;
+    popsift_hip_params p{};
+    int                levels = 3, L = 6;
+    HostTables         tab{};
+    SiftConsts         sc{};
+    hipStream_t        stream = nullptr;
+    hipEvent_t         ev_begin = nullptr, ev_end = nullptr;
+
+    /* image geometry */
+    int  in_w = 0, in_h = 0;
+    int  frozen_octaves = -1;
+    bool have_image = false, finished = false, fetched_counts = false;
+
+    /* device memory (grow-only) */
+    void*   d_input = nullptr;
+    size_t  input_cap = 0;
+    float*  d_arena = nullptr;
+    size_t  arena_cap = 0; /* floats */
+    PyrDesc pd{};
+    InitExt* d_iext = nullptr;
+    Ext*     d_ext = nullptr;
+    popsift_hip_feature* d_feats = nullptr;
+    size_t   ext_cap = 0; /* entries in d_iext/d_ext/d_feats */
+    int*     d_map = nullptr;
+    float*   d_desc = nullptr;
+    int      desc_cap = 0;
+    Counters* d_ct = nullptr;
+    Counters* h_ct = nullptr; /* pinned */
+
+    /* profiling */
+    int                    profile = 0;
+    std::vector<EventPair> blur_events;
+    size_t                 blur_events_used = 0;
+    popsift_hip_report     rep{};
+
+    char err[256] = {0};
+};
+
+namespace {
+
+int fail(popsift_hip_ctx* c, int code, const char* fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return fail((c), e__ == hipErrorOutOfMemory ? POPSIFT_HIP_ERR_OOM : POPSIFT_HIP_ERR_DEVICE, \
+                        "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__));          \
+    } while (0)
+
+/* GaussInfo::getSpan, gauss_filter.cu:274-328 */
+int span_for(int gauss_mode, float sigma)
+{
+    if (gauss_mode == POPSIFT_HIP_GAUSS_OPENCV_COMPUTE) {
+        int span = int(roundf(2.0f * 4.0f * sigma + 1.0f)) | 1;
+        span >>= 1;
+        span += 1;
+        return std::min<int>(span, PS_GA - 1);
+    }
+    return std::min<int>(ceilf(4.0f * sigma) + 1, PS_GA - 1);
+}
+
+/* init_filter (inc table; dd[0] is identical to inc[0]) gauss_filter.cu:163-181,340-372
+ * and init_constants sift_constants.cu:22-31 */
+void init_tables(popsift_hip_ctx* c)
+{
+    const popsift_hip_params& p = c->p;
+    const float sigma0 = p.sigma;
+    const int   levels = c->levels;
+    const float initial_blur = p.assume_initial_blur ? p.initial_blur * powf(2.0f, p.upscale_factor) : 0.0f;
+    HostTables& t = c->tab;
+    memset(&t, 0, sizeof(t));
+    t.sigma[0] = p.assume_initial_blur ? sqrtf(fabsf(sigma0 * sigma0 - initial_blur * initial_blur)) : sigma0;
+    for (int lvl = 1; lvl < c->L; lvl++) {
+        const float sigmaP = sigma0 * powf(2.0f, (float)(lvl - 1) / (float)levels);
+        const float sigmaS = sigma0 * powf(2.0f, (float)(lvl) / (float)levels);
+        t.sigma[lvl] = sqrtf(sigmaS * sigmaS - sigmaP * sigmaP);
+    }
+    for (int level = 0; level < POPSIFT_HIP_MAX_LEVELS; level++) {
+        t.span[level] = std::min(span_for(p.gauss_mode, t.sigma[level]), PS_GA - 1);
+        const float sig = t.sigma[level];
+        const int   spn = t.span[level];
+        float*      f = &t.filter[level * PS_GA];
+        double      sum = 1.0;
+        f[0] = 1.0f;
+        for (int x = 1; x < spn; x++) {
+            const float val = (float)exp(-0.5 * (pow(double(x) / sig, 2.0)));
+            f[x] = val;
+            sum += 2.0f * val;
+        }
+        for (int x = 0; x < spn; x++) f[x] = (float)(f[x] / sum);
+        for (int x = spn; x < PS_GA; x++) f[x] = 0.0f;
+    }
+    SiftConsts& sc = c->sc;
+    sc.sigma0 = sigma0;
+    sc.sigma_k = powf(2.0f, 1.0f / levels);
+    sc.edge_limit = p.edge_limit;
+    sc.threshold = p.threshold * 0.5f * 255.0f / levels; /* Config::getPeakThreshold, sift_conf.cu:275-278 */
+    sc.max_extrema = p.max_extrema;
+    sc.norm_multi = p.norm_multi;
+    sc.norm_mode = p.norm_mode;
+    sc.sift_mode = p.sift_mode;
+    sc.grid_size = p.filter_grid_size > 0 ? p.filter_grid_size : 1;
+    sc.up_fac_int = (int)p.upscale_factor;
+}
+
+/* PopSift::private_init, popsift.cpp:89-120 */
+void plan_dims(const popsift_hip_ctx* c, int w, int h, int octaves_cfg, int* n_oct, int* bw, int* bh)
+{
+    const float scaleFactor = 1.0f / powf(2.0f, -c->p.upscale_factor);
+    int         oct = octaves_cfg;
+    if (oct < 0) oct = std::max(int(floorf(logf((float)std::min(w, h)) / logf(2.0f)) - 3.0f + scaleFactor), 1);
+    oct = std::min(oct, PS_MAX_OCT);
+    *n_oct = oct;
+    *bw = (int)ceilf(w * scaleFactor);
+    *bh = (int)ceilf(h * scaleFactor);
+}
+
+template <typename T>
+int grow(popsift_hip_ctx* c, T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    if (*ptr) HIP_TRY(c, hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(c, hipMalloc((void**)ptr, need * sizeof(T)));
+    *cap = need;
+    return 0;
+}
+
+int ensure_desc_cap(popsift_hip_ctx* c, int need)
+{
+    if (need <= c->desc_cap) return 0;
+    if (c->d_desc) HIP_TRY(c, hipFree(c->d_desc));
+    if (c->d_map) HIP_TRY(c, hipFree(c->d_map));
+    c->d_desc = nullptr;
+    c->d_map = nullptr;
+    c->desc_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_desc, (size_t)need * 128 * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_map, (size_t)need * sizeof(int)));
+    c->desc_cap = need;
+    return 0;
+}
+
+/* Pyramid::Pyramid / resetDimensions: sizes for this image, grow-only arena */
+int prepare_geometry(popsift_hip_ctx* c, int w, int h)
+{
+    int n_oct, bw, bh;
+    plan_dims(c, w, h, c->frozen_octaves, &n_oct, &bw, &bh);
+    c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */
+    if (bw < 1 || bh < 1) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image is empty");
+
+    PyrDesc& pd = c->pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.n_oct = n_oct;
+    pd.levels = c->levels;
+    pd.L = c->L;
+    size_t total = 0;
+    int    ow = bw, oh = bh, tiles = 0;
+    for (int o = 0; o < n_oct; o++) {
+        OctDesc& od = pd.o[o];
+        od.w = ow;
+        od.h = oh;
+        od.pitch = (ow + PITCH_ALIGN - 1) / PITCH_ALIGN * PITCH_ALIGN;
+        od.plane_stride = (int64_t)od.pitch * oh;
+        od.tile_begin = tiles;
+        tiles += ((ow + extrema_tile_w() - 1) / extrema_tile_w()) * ((oh + extrema_tile_h() - 1) / extrema_tile_h()) *
+                 c->levels;
+        total += (size_t)od.plane_stride * (size_t)(2 * c->L - 1);
+        ow = (int)ceilf(ow / 2.0f); /* sift_pyramid.cu:132-133 */
+        oh = (int)ceilf(oh / 2.0f);
+    }
+    pd.total_tiles = tiles;
+    if (int rc = grow(c, &c->d_arena, &c->arena_cap, total)) return rc;
+    float* p = c->d_arena;
+    for (int o = 0; o < n_oct; o++) {
+        OctDesc& od = pd.o[o];
+        od.data = p;
+        p += od.plane_stride * c->L;
+        od.dog = p;
+        p += od.plane_stride * (c->L - 1);
+    }
+    const size_t need_ext = (size_t)n_oct * (size_t)c->sc.max_extrema;
+    if (need_ext > c->ext_cap) {
+        size_t cap0 = c->ext_cap, cap1 = c->ext_cap, cap2 = c->ext_cap;
+        if (int rc = grow(c, &c->d_iext, &cap0, need_ext)) return rc;
+        if (int rc = grow(c, &c->d_ext, &cap1, need_ext)) return rc;
+        if (int rc = grow(c, &c->d_feats, &cap2, need_ext)) return rc;
+        c->ext_cap = need_ext;
+    }
+    /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
+    if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
+        return rc;
+    c->in_w = w;
+    c->in_h = h;
+    c->rep.num_octaves = n_oct;
+    c->rep.base_w = bw;
+    c->rep.base_h = bh;
+    double px = 0;
+    for (int o = 0; o < n_oct; o++) px += (double)pd.o[o].w * pd.o[o].h;
+    c->rep.pyramid_pixels = px;
+    return 0;
+}
+
+int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, double alg_bytes)
+{
+    if (c->profile) {
+        if (c->blur_events_used == c->blur_events.size()) {
+            EventPair ep;
+            HIP_TRY(c, hipEventCreate(&ep.a));
+            HIP_TRY(c, hipEventCreate(&ep.b));
+            c->blur_events.push_back(ep);
+        }
+        EventPair& ep = c->blur_events[c->blur_events_used++];
+        ep.bytes = alg_bytes;
+        HIP_TRY(c, hipEventRecord(ep.a, c->stream));
+        HIP_TRY(c, launch_blur(a, mode, span, c->stream));
+        HIP_TRY(c, hipEventRecord(ep.b, c->stream));
+    } else {
+        HIP_TRY(c, launch_blur(a, mode, span, c->stream));
+    }
+    return 0;
+}
+
+/* Pyramid::build_pyramid default branch (s_pyramid_build.cu:549-588) */
+int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch)
+{
+    const PyrDesc& pd = c->pd;
+    const int      twd = blur_tile_w(), thd = blur_tile_h();
+    for (int o = 0; o < pd.n_oct; o++) {
+        const OctDesc& od = pd.o[o];
+        BlurArgs       a{};
+        a.w = od.w;
+        a.h = od.h;
+        a.pitch = od.pitch;
+        a.tiles_x = (od.w + twd - 1) / twd;
+        a.tiles_y = (od.h + thd - 1) / thd;
+        const double px = (double)od.w * od.h;
+        for (int level = 0; level < pd.L; level++) {
+            memcpy(a.taps.g, &c->tab.filter[level * PS_GA], sizeof(a.taps.g));
+            a.dst = od.data + level * od.plane_stride;
+            if (level == 0) {
+                if (o == 0) {
+                    /* horiz_from_input_image, s_pyramid_build.cu:96-126 */
+                    float shift = 0.5f;
+                    if (c->p.sift_mode == POPSIFT_HIP_SIFT_POPSIFT || c->p.sift_mode == POPSIFT_HIP_SIFT_VLFEAT)
+                        shift = 0.5f * powf(2.0f, c->p.upscale_factor - 0);
+                    a.src = nullptr;
+                    a.dog = nullptr;
+                    a.in = d_img;
+                    a.in_w = c->in_w;
+                    a.in_h = c->in_h;
+                    a.in_pitch = pitch;
+                    a.shift = shift;
+                    const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * px;
+                    if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], bytes)) return rc;
+                } else {
+                    const OctDesc& pv = pd.o[o - 1];
+                    HIP_TRY(c, launch_decimate(pv.data + (pd.L - 3) * pv.plane_stride, pv.w, pv.h, pv.pitch, a.dst,
+                                               od.w, od.h, od.pitch, c->stream));
+                }
+            } else {
+                a.src = od.data + (level - 1) * od.plane_stride;
+                a.dog = od.dog + (level - 1) * od.plane_stride;
+                a.in = nullptr;
+                /* read plane l-1 once, write plane l and DoG l-1 once: 12 B / pixel */
+                if (int rc = blur_launch(c, a, 0, c->tab.span[level], 12.0 * px)) return rc;
+            }
+        }
+    }
+    return 0;
+}
+
+/* Pyramid::step2 + prep_features: extrema -> orientation -> scan -> descriptors -> features */
+int enqueue_keypoint_stages(popsift_hip_ctx* c)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
+    HIP_TRY(c, launch_extrema(c->pd, c->sc, c->d_ct, c->d_iext, c->stream));
+    HIP_TRY(c, launch_orientation(c->pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 2048, c->stream));
+    HIP_TRY(c, launch_scan(c->pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->desc_cap, c->stream));
+    HIP_TRY(c, launch_descriptors(c->pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 4096,
+                                  c->stream));
+    HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32, int w, int h, int pitch)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (!img || w <= 0 || h <= 0 || pitch < w) return fail(c, POPSIFT_HIP_ERR_INVALID, "bad image arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->have_image && !c->finished) {
+        /* one image in flight per context: drain the previous one */
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (int rc = prepare_geometry(c, w, h)) return rc;
+    const size_t esz = is_f32 ? 4 : 1;
+    const void*  d_img = img;
+    int          dpitch = pitch;
+    if (!on_device) {
+        size_t cap = c->input_cap;
+        char*  buf = (char*)c->d_input;
+        if (int rc = grow(c, &buf, &cap, (size_t)w * h * esz)) return rc;
+        c->d_input = buf;
+        c->input_cap = cap;
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_input, (size_t)w * esz, img, (size_t)pitch * esz, (size_t)w * esz, h,
+                                    hipMemcpyHostToDevice, c->stream));
+        d_img = c->d_input;
+        dpitch = w;
+    }
+    c->blur_events_used = 0;
+    HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
+    if (int rc = enqueue_pyramid(c, d_img, is_f32, dpitch)) return rc;
+    if (int rc = enqueue_keypoint_stages(c)) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
+    c->have_image = true;
+    c->finished = false;
+    return 0;
+}
+
+int finish(popsift_hip_ctx* c)
+{
+    if (!c->have_image) return fail(c, POPSIFT_HIP_ERR_STATE, "no image submitted");
+    if (c->finished) return 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_ct->ori_total <= c->desc_cap) break;
+        /* more descriptors than the buffer holds (the reference reallocates between stages,
+         * sift_pyramid.cu:179-209): grow and redo the keypoint stages of this image */
+        if (int rc = ensure_desc_cap(c, c->h_ct->ori_total + c->h_ct->ori_total / 8 + 1024)) return rc;
+        if (int rc = enqueue_keypoint_stages(c)) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
+    }
+    popsift_hip_report& r = c->rep;
+    for (int o = 0; o < PS_MAX_OCT; o++) {
+        r.ext_ct[o] = c->h_ct->ext_ct[o];
+        r.ori_ct[o] = c->h_ct->ori_ct[o];
+    }
+    r.ext_total = c->h_ct->ext_total;
+    r.ori_total = std::min(c->h_ct->ori_total, c->desc_cap);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) r.ms_device = ms;
+    r.ms_blur = 0.0f;
+    r.blur_launches = 0;
+    r.blur_alg_bytes = 0.0;
+    for (size_t i = 0; i < c->blur_events_used; i++) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, c->blur_events[i].a, c->blur_events[i].b) == hipSuccess) {
+            r.ms_blur += t;
+            r.blur_launches++;
+            r.blur_alg_bytes += c->blur_events[i].bytes;
+        }
+    }
+    c->finished = true;
+    return 0;
+}
+
+int plane_ptr(popsift_hip_ctx* c, int octave, int kind, int level, float** p, const OctDesc** odp)
+{
+    if (!c || !c->have_image) return POPSIFT_HIP_ERR_STATE;
+    if (octave < 0 || octave >= c->pd.n_oct || level < 0) return fail(c, POPSIFT_HIP_ERR_INVALID, "bad octave/level");
+    const OctDesc& od = c->pd.o[octave];
+    if (kind == 0 && level < c->L)
+        *p = od.data + level * od.plane_stride;
+    else if (kind == 1 && level < c->L - 1)
+        *p = od.dog + level * od.plane_stride;
+    else
+        return fail(c, POPSIFT_HIP_ERR_INVALID, "bad plane kind/level");
+    *odp = &od;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void popsift_hip_default_params(popsift_hip_params* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->octaves = -1;
+    p->levels = 3;
+    p->sigma = 1.6f;
+    p->edge_limit = 10.0f;
+    p->threshold = 0.04f;
+    p->upscale_factor = 1.0f;
+    p->sift_mode = POPSIFT_HIP_SIFT_POPSIFT;
+    p->gauss_mode = POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE;
+    p->desc_mode = POPSIFT_HIP_DESC_LOOP;
+    p->norm_mode = POPSIFT_HIP_NORM_ROOTSIFT;
+    p->norm_multi = 0;
+    p->max_extrema = 100000;
+    p->assume_initial_blur = 1;
+    p->initial_blur = 0.5f;
+    p->filter_grid_size = 2;
+}
+
+const char* popsift_hip_version(void) { return "popsift_hip 0.1 (gfx950, wave64)"; }
+
+const char* popsift_hip_strerror(int status)
+{
+    switch (status) {
+    case POPSIFT_HIP_OK: return "ok";
+    case POPSIFT_HIP_ERR_INVALID: return "invalid argument or unsupported mode";
+    case POPSIFT_HIP_ERR_DEVICE: return "HIP runtime error";
+    case POPSIFT_HIP_ERR_NO_DEVICE: return "no usable GPU";
+    case POPSIFT_HIP_ERR_OOM: return "out of memory";
+    case POPSIFT_HIP_ERR_STATE: return "call sequence error";
+    case POPSIFT_HIP_ERR_TOO_SMALL: return "buffer too small";
+    }
+    return "unknown status";
+}
+
+const char* popsift_hip_last_error(const popsift_hip_ctx* ctx) { return ctx ? ctx->err : ""; }
+
+int popsift_hip_device_count(int* count)
+{
+    if (!count) return POPSIFT_HIP_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *count = 0;
+        return POPSIFT_HIP_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return n > 0 ? POPSIFT_HIP_OK : POPSIFT_HIP_ERR_NO_DEVICE;
+}
+
+int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_ctx** out)
+{
+    if (!p || !out) return POPSIFT_HIP_ERR_INVALID;
+    *out = nullptr;
+    /* gauss_filter.cu:131-144: sigma > 2 or too many levels is fatal in the reference */
+    if (!(p->sigma > 0.0f) || p->sigma > 2.0f) return POPSIFT_HIP_ERR_INVALID;
+    if (p->levels > POPSIFT_HIP_MAX_LEVELS - 3) return POPSIFT_HIP_ERR_INVALID;
+    if (p->gauss_mode != POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE && p->gauss_mode != POPSIFT_HIP_GAUSS_OPENCV_COMPUTE)
+        return POPSIFT_HIP_ERR_INVALID;
+    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP) return POPSIFT_HIP_ERR_INVALID;
+    if (p->sift_mode < 0 || p->sift_mode > 2 || p->norm_mode < 0 || p->norm_mode > 1) return POPSIFT_HIP_ERR_INVALID;
+    if (p->max_extrema < 1 || !(p->edge_limit > 0.0f)) return POPSIFT_HIP_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return POPSIFT_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return POPSIFT_HIP_ERR_INVALID;
+
+    popsift_hip_ctx* c = new (std::nothrow) popsift_hip_ctx();
+    if (!c) return POPSIFT_HIP_ERR_OOM;
+    c->device = device;
+    c->p = *p;
+    c->levels = std::max(2, p->levels); /* popsift.cpp:71 */
+    c->L = c->levels + 3;
+    c->frozen_octaves = p->octaves;
+    init_tables(c);
+    int rc = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(device));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreate(&c->ev_begin));
+        HIP_TRY(c, hipEventCreate(&c->ev_end));
+        HIP_TRY(c, hipMalloc((void**)&c->d_ct, sizeof(Counters)));
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_ct, sizeof(Counters), hipHostMallocDefault));
+        memset(c->h_ct, 0, sizeof(Counters));
+        return 0;
+    }();
+    if (rc) {
+        popsift_hip_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
+{
+    if (!c) return POPSIFT_HIP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& ep : c->blur_events) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->d_input) (void)hipFree(c->d_input);
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_iext) (void)hipFree(c->d_iext);
+    if (c->d_ext) (void)hipFree(c->d_ext);
+    if (c->d_feats) (void)hipFree(c->d_feats);
+    if (c->d_map) (void)hipFree(c->d_map);
+    if (c->d_desc) (void)hipFree(c->d_desc);
+    if (c->d_ct) (void)hipFree(c->d_ct);
+    if (c->h_ct) (void)hipHostFree(c->h_ct);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_get_gauss_table(const popsift_hip_ctx* c, float* filter, int* span, float* sigma, int* n_levels)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (filter) memcpy(filter, c->tab.filter, sizeof(float) * (size_t)c->L * PS_GA);
+    if (span) memcpy(span, c->tab.span, sizeof(int) * (size_t)c->L);
+    if (sigma) memcpy(sigma, c->tab.sigma, sizeof(float) * (size_t)c->L);
+    if (n_levels) *n_levels = c->L;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_submit_u8(popsift_hip_ctx* c, const uint8_t* img, int w, int h, int pitch)
+{
+    return submit_common(c, img, 0, 0, w, h, pitch);
+}
+int popsift_hip_submit_f32(popsift_hip_ctx* c, const float* img, int w, int h, int pitch)
+{
+    return submit_common(c, img, 0, 1, w, h, pitch);
+}
+int popsift_hip_submit_dev_u8(popsift_hip_ctx* c, const void* d_img, int w, int h, int pitch)
+{
+    return submit_common(c, d_img, 1, 0, w, h, pitch);
+}
+int popsift_hip_submit_dev_f32(popsift_hip_ctx* c, const void* d_img, int w, int h, int pitch)
+{
+    return submit_common(c, d_img, 1, 1, w, h, pitch);
+}
+
+int popsift_hip_wait(popsift_hip_ctx* c, int* n_features, int* n_descriptors)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = finish(c)) return rc;
+    if (n_features) *n_features = c->rep.ext_total;
+    if (n_descriptors) *n_descriptors = c->rep.ori_total;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_fetch(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t feats_cap, float* desc, size_t desc_cap)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = finish(c)) return rc;
+    const size_t nf = (size_t)c->rep.ext_total, nd = (size_t)c->rep.ori_total;
+    if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
+    if (feats_cap < nf || desc_cap < nd * 128) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, c->d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->stream));
+    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_results_dev(popsift_hip_ctx* c, const void** d_feats, const void** d_desc)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = finish(c)) return rc;
+    if (d_feats) *d_feats = c->d_feats;
+    if (d_desc) *d_desc = c->d_desc;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_get_report(const popsift_hip_ctx* c, popsift_hip_report* rep)
+{
+    if (!c || !rep) return POPSIFT_HIP_ERR_INVALID;
+    *rep = c->rep;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_set_profile(popsift_hip_ctx* c, int profile)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    c->profile = profile ? 1 : 0;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_octave_dims(const popsift_hip_ctx* c, int octave, int* w, int* h)
+{
+    if (!c || !c->have_image || octave < 0 || octave >= c->pd.n_oct) return POPSIFT_HIP_ERR_INVALID;
+    if (w) *w = c->pd.o[octave].w;
+    if (h) *h = c->pd.o[octave].h;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_download_plane(popsift_hip_ctx* c, int octave, int kind, int level, float* out)
+{
+    float*         p = nullptr;
+    const OctDesc* od = nullptr;
+    if (!out) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = plane_ptr(c, octave, kind, level, &p, &od)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy2D(out, (size_t)od->w * 4, p, (size_t)od->pitch * 4, (size_t)od->w * 4, od->h,
+                           hipMemcpyDeviceToHost));
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_upload_plane(popsift_hip_ctx* c, int octave, int kind, int level, const float* in)
+{
+    float*         p = nullptr;
+    const OctDesc* od = nullptr;
+    if (!in) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = plane_ptr(c, octave, kind, level, &p, &od)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy2D(p, (size_t)od->pitch * 4, in, (size_t)od->w * 4, (size_t)od->w * 4, od->h,
+                           hipMemcpyHostToDevice));
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_download_extrema(popsift_hip_ctx* c, popsift_hip_extremum* out, size_t cap, int* n)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = finish(c)) return rc;
+    const int total = c->rep.ext_total;
+    if (n) *n = total;
+    if (!out) return POPSIFT_HIP_OK;
+    if (cap < (size_t)total) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<InitExt> tmp((size_t)std::max(c->sc.max_extrema, 1));
+    size_t               k = 0;
+    for (int o = 0; o < c->pd.n_oct; o++) {
+        const int cnt = c->rep.ext_ct[o];
+        if (cnt <= 0) continue;
+        HIP_TRY(c, hipMemcpy(tmp.data(), c->d_iext + (size_t)o * c->sc.max_extrema, (size_t)cnt * sizeof(InitExt),
+                             hipMemcpyDeviceToHost));
+        for (int i = 0; i < cnt; i++, k++) {
+            out[k].xpos = tmp[i].xpos;
+            out[k].ypos = tmp[i].ypos;
+            out[k].lpos = tmp[i].lpos;
+            out[k].sigma = tmp[i].sigma;
+            out[k].octave = o;
+            out[k].cell = tmp[i].cell;
+        }
+    }
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* c)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (!c->have_image) return fail(c, POPSIFT_HIP_ERR_STATE, "no image submitted");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->blur_events_used = 0;
+    HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
+    if (int rc = enqueue_keypoint_stages(c)) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
+    c->finished = false;
+    return POPSIFT_HIP_OK;
+}
+
+} /* extern "C" */

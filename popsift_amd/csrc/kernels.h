@@ -1,0 +1,46 @@
+/* kernels.h -- host-callable launchers of the HIP kernels (internal). */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sift_types.h"
+
+namespace popsift_hip {
+
+struct Taps {
+    float g[PS_GA];
+};
+
+struct BlurArgs {
+    const float* src; /* plane l-1 (MODE 0)                     */
+    float*       dst; /* plane l                                */
+    float*       dog; /* DoG plane l-1 (MODE 0)                 */
+    int          w, h, pitch;
+    int          tiles_x, tiles_y;
+    const void*  in; /* input image (MODE 1: u8, MODE 2: f32)  */
+    int          in_w, in_h, in_pitch;
+    float        shift;
+    Taps         taps;
+};
+
+int        blur_tile_w();
+int        blur_tile_h();
+hipError_t launch_blur(const BlurArgs& a, int mode, int span, hipStream_t s);
+hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* dst, int dw, int dh,
+                           int dpitch, hipStream_t s);
+
+/* extrema.hip */
+int        extrema_tile_w();
+int        extrema_tile_h();
+hipError_t launch_extrema(const PyrDesc& pd, const SiftConsts& sc, Counters* ct, InitExt* iext, hipStream_t s);
+
+/* keypoint.hip */
+hipError_t launch_orientation(const PyrDesc& pd, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
+                              Ext* ext, int blocks, hipStream_t s);
+hipError_t launch_scan(const PyrDesc& pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* map, int desc_cap,
+                       hipStream_t s);
+hipError_t launch_descriptors(const PyrDesc& pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
+                              const int* map, float* desc, int desc_cap, int blocks, hipStream_t s);
+hipError_t launch_prep(const SiftConsts& sc, const Counters* ct, const Ext* ext, popsift_hip_feature* feats,
+                       int desc_cap, int blocks, hipStream_t s);
+
+}  // namespace popsift_hip

@@ -1,0 +1,445 @@
+/*
+ * keypoint.hip -- orientation assignment, orientation prefix sum, 128-D "loop"
+ * descriptor + normalisation, Feature assembly.  All kernels size themselves
+ * from the device-resident counters (grid-stride), so the host never has to
+ * read a count back between stages (the reference blocks on the counters twice
+ * per image: s_orientation.cu:351, sift_desc.cu:60-61).
+ *
+ * Replaces:
+ *   ori_par               s_orientation.cu:60-242   -> k_orientation (1 wave / extremum)
+ *   ori_prefix_sum        s_orientation.cu:303-345  -> k_scan (1 workgroup, wave64 scans)
+ *   ext_desc_loop(+_sub)  s_desc_loop.cu:19-161     -> k_descriptor (1 workgroup / descriptor)
+ *   normalize_histogram   s_desc_normalize.h:14-33, s_desc_norm_rs.h, s_desc_norm_l2.h
+ *                                                   -> fused into k_descriptor
+ *   prep_features         sift_pyramid.cu:249-279   -> k_prep
+ */
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "sift_types.h"
+
+namespace popsift_hip {
+namespace {
+
+/* sift_constants.h:22-29: float constants */
+constexpr float F_PI = 3.14159265358979323846f;
+constexpr float F_PI2 = 2.0f * 3.14159265358979323846f;
+constexpr float            ORI_WINFACTOR = 1.5f;
+constexpr float            DESC_MAGNIFY = 3.0f;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+/* clamped extrema counts -> exclusive prefix (uniform, <= 20 entries) */
+__device__ __forceinline__ int ext_prefix(const Counters* ct, const SiftConsts& sc, int n_oct, int* ps)
+{
+    int acc = 0;
+    for (int o = 0; o < n_oct; o++) {
+        ps[o] = acc;
+        acc += min(ct->ext_ct[o], sc.max_extrema);
+    }
+    ps[n_oct] = acc;
+    return acc;
+}
+
+/* s_gradiant.h:55-69; the caller keeps (x, y) inside [1,w-2]x[1,h-2] */
+__device__ __forceinline__ void get_gradiant(float& grad, float& theta, int x, int y, const float* pl, int pitch)
+{
+    const float* c = pl + (size_t)y * pitch + x;
+    const float  dx = c[1] - c[-1];
+    const float  dy = c[pitch] - c[-pitch];
+    grad = hypotf(dx, dy);
+    theta = atan2f(dy, dx);
+}
+
+/* ------------------------------------------------------------ orientation */
+
+__global__ __launch_bounds__(256) void k_orientation(PyrDesc pd, SiftConsts sc, const Counters* __restrict__ ct,
+                                                     const InitExt* __restrict__ iext, Ext* __restrict__ ext)
+{
+    __shared__ float s_hist[4][PS_ORI_NBINS + 4];
+    const int        wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float*           hist = s_hist[wave];
+
+    __shared__ int ps[PS_MAX_OCT + 1];
+    if (threadIdx.x == 0) ext_prefix(ct, sc, pd.n_oct, ps);
+    __syncthreads();
+    const int total = ps[pd.n_oct];
+
+    for (int g = blockIdx.x * 4 + wave; g < total; g += gridDim.x * 4) {
+        int o = 0;
+        while (o + 1 < pd.n_oct && g >= ps[o + 1]) o++;
+        const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - ps[o])];
+        const OctDesc& od = pd.o[o];
+        const int      w = od.w, h = od.h;
+        const int      lvl = min(max(ie.lpos, 0), pd.L - 1);
+        const float*   layer = od.data + lvl * od.plane_stride;
+
+        if (lane < PS_ORI_NBINS) hist[lane] = 0.0f;
+        wave_lds_sync();
+
+        const float x = ie.xpos, y = ie.ypos, sig = ie.sigma;
+        const float sigw = ORI_WINFACTOR * sig;
+        const int   rad = (int)roundf(3.0f * sigw);
+        const float factor = -0.5f / (sigw * sigw);
+        const int   sq_thres = rad * rad;
+        const int   xmin = max(1, (int)roundf(x) - rad);
+        const int   xmax = min(w - 2, (int)roundf(x) + rad);
+        const int   ymin = max(1, (int)roundf(y) - rad);
+        const int   ymax = min(h - 2, (int)roundf(y) + rad);
+        const int   wx = xmax - xmin + 1;
+        const int   hy = ymax - ymin + 1;
+        const int   loops = wx * hy;
+
+        for (int i = lane; i < loops; i += 64) {
+            const int yy = i / wx + ymin;
+            const int xx = i - (i / wx) * wx + xmin;
+            float     grad, theta;
+            get_gradiant(grad, theta, xx, yy, layer, od.pitch);
+            const float dx = xx - x;
+            const float dy = yy - y;
+            const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
+            if (sq_dist <= sq_thres) {
+                const float weight = grad * expf(sq_dist * factor);
+                int         bidx = (int)roundf((float)PS_ORI_NBINS * (theta + F_PI) / F_PI2);
+                bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
+                if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], weight);
+            }
+        }
+        wave_lds_sync();
+
+        /* lanes 0..35 own one bin each; 6 circular box-filter passes (s_orientation.cu:142-160) */
+        const int bin = lane;
+        const int prev = (bin == 0) ? PS_ORI_NBINS - 1 : bin - 1;
+        const int next = (bin >= PS_ORI_NBINS - 1) ? 0 : bin + 1;
+        float     hv = (lane < PS_ORI_NBINS) ? hist[lane] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 6; pass++) {
+            const float hp = __shfl(hv, prev);
+            const float hn = __shfl(hv, next);
+            hv = (hp + hv + hn) / 3.0f;
+        }
+        const float hp = __shfl(hv, prev);
+        const float hn = __shfl(hv, next);
+
+        bool        predicate = (lane < PS_ORI_NBINS) && (hv > fmaxf(hp, hn));
+        const float num = predicate ? 3.0f * hp - 4.0f * hv + 1.0f * hn : 0.0f;
+        const float denB = predicate ? 2.0f * (hp - 2.0f * hv + hn) : 1.0f;
+        const float newbin = num / denB;
+        predicate = (predicate && newbin >= 0.0f && newbin <= 2.0f);
+        const float refined = predicate ? prev + newbin : -1.0f;
+        const float yval = predicate ? -(num * num) / (4.0f * denB) + hp : -INFINITY;
+
+        /* top-4 by yval, ties to the lower bin (replaces BitonicSort::Warp32::sort64) */
+        bool  used = false;
+        float best0 = 0.0f;
+        float my_angle[POPSIFT_HIP_ORI_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int   angles = 0;
+#pragma unroll
+        for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) {
+            float bv = used ? -INFINITY : yval;
+            int   bi = used ? 128 + lane : lane; /* used lanes lose every tie */
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+                const float ov = __shfl_xor(bv, s);
+                const int   oi = __shfl_xor(bi, s);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            bi &= 127;
+            if (k == 0) best0 = bv;
+            const float chosen_raw = __shfl(refined, bi);
+            if (lane == bi) used = true;
+            /* yval is sorted descending, so the accepted ones are a prefix: slot k is static */
+            if (bv >= 0.8f * best0) {
+                float chosen_bin = chosen_raw;
+                if (chosen_bin >= PS_ORI_NBINS) chosen_bin -= PS_ORI_NBINS;
+                my_angle[k] = fmaf(F_PI2 * chosen_bin, 1.0f / PS_ORI_NBINS, -F_PI);
+                angles = k + 1;
+            }
+        }
+        if (lane == 0) {
+            Ext e;
+            e.xpos = ie.xpos;
+            e.ypos = ie.ypos;
+            e.lpos = ie.lpos;
+            e.sigma = ie.sigma;
+            e.octave = o;
+            e.num_ori = angles;
+            e.idx_ori = 0;
+#pragma unroll
+            for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) e.orientation[k] = my_angle[k];
+            ext[g] = e;
+        }
+        wave_lds_sync();
+    }
+}
+
+/* ------------------------------------------------------------------- scan */
+
+__global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counters* __restrict__ ct,
+                                               Ext* __restrict__ ext, int* __restrict__ map, int desc_cap)
+{
+    __shared__ int s_wsum[16];
+    __shared__ int s_carry;
+    __shared__ int s_ps[PS_MAX_OCT + 1];
+    const int      tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid == 0) {
+        int acc = 0;
+        for (int o = 0; o < PS_MAX_OCT; o++) {
+            const int c = (o < pd.n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
+            ct->ext_ct[o] = c; /* the reference clamps with atomicMin, s_extrema.cu:558 */
+            ct->ext_ps[o] = acc;
+            s_ps[o] = acc;
+            acc += c;
+        }
+        s_ps[PS_MAX_OCT] = acc;
+        ct->ext_total = acc;
+        s_carry = 0;
+    }
+    __syncthreads();
+    const int total = s_ps[PS_MAX_OCT];
+
+    for (int base = 0; base < total; base += 1024) {
+        const int  g = base + tid;
+        const bool valid = g < total;
+        const int  self = valid ? ext[g].num_ori : 0;
+        /* inclusive wave64 scan */
+        int incl = self;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int v = __shfl_up(incl, s);
+            if (lane >= s) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            int v = (lane < 16) ? s_wsum[lane] : 0;
+            int inc2 = v;
+#pragma unroll
+            for (int s = 1; s < 16; s <<= 1) {
+                const int u = __shfl_up(inc2, s);
+                if (lane >= s) inc2 += u;
+            }
+            if (lane < 16) s_wsum[lane] = inc2 - v; /* exclusive */
+        }
+        __syncthreads();
+        const int carry = s_carry;
+        const int excl = carry + s_wsum[wave] + incl - self;
+        if (valid) {
+            ext[g].idx_ori = excl;
+            for (int k = 0; k < self; k++)
+                if (excl + k < desc_cap) map[excl + k] = g;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = excl + self;
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        const int ori_total = s_carry;
+        /* per-octave orientation counts (s_orientation.cu:319-339) */
+        int acc = 0;
+        for (int o = 0; o < PS_MAX_OCT; o++) {
+            int c = 0;
+            if (o < pd.n_oct && ct->ext_ct[o] > 0) {
+                const int fe = s_ps[o], le = s_ps[o + 1] - 1;
+                c = ext[le].idx_ori + ext[le].num_ori - ext[fe].idx_ori;
+            }
+            ct->ori_ct[o] = c;
+            ct->ori_ps[o] = acc;
+            acc += c;
+        }
+        ct->ori_total = ori_total;
+    }
+}
+
+/* ------------------------------------------------------------- descriptor */
+
+/*
+ * One workgroup (256 lanes) per (extremum, orientation).  The reference gives
+ * every one of the 16 cells its own warp, which re-computes the gradient of
+ * each patch pixel for up to four overlapping cells (s_desc_loop.cu:78-122).
+ * Here each patch pixel is visited once: its gradient is computed once and
+ * its contribution is spread to the (at most) 2x2 cells whose unit square
+ * contains it -- the same sample set and weights, a different summation order.
+ */
+__global__ __launch_bounds__(256) void k_descriptor(PyrDesc pd, SiftConsts sc, const Counters* __restrict__ ct,
+                                                    const Ext* __restrict__ ext, const int* __restrict__ map,
+                                                    float* __restrict__ desc, int desc_cap)
+{
+    __shared__ float s_hist[128];
+    __shared__ float s_red[4];
+    const int        tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int        total = min(ct->ori_total, desc_cap);
+    const float      M_4RPI = 4.0f / F_PI;
+
+    for (int d = blockIdx.x; d < total; d += gridDim.x) {
+        const Ext      e = ext[map[d]];
+        const float    ang = e.orientation[min(max(d - e.idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1)];
+        const OctDesc& od = pd.o[e.octave];
+        const int      width = od.w, height = od.h;
+        const int      lvl = min(max(e.lpos, 0), pd.L - 1);
+        const float*   layer = od.data + lvl * od.plane_stride;
+
+        if (tid < 128) s_hist[tid] = 0.0f;
+        __syncthreads();
+
+        const float x = e.xpos, y = e.ypos;
+        const float SBP = fabsf(DESC_MAGNIFY * e.sigma);
+        if (SBP != 0.0f) {
+            float sin_t, cos_t;
+            sincosf(ang, &sin_t, &cos_t);
+            const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+            const float crsbp = cos_t / SBP, srsbp = sin_t / SBP;
+            const float bsz = fabsf(csbp) + fabsf(ssbp);
+            /* union of the 16 cell boxes: cell centres reach 1.5 * bsz, each box adds bsz */
+            const float ext_r = 2.5f * bsz;
+            const int   xmin = max(1, (int)floorf(x - ext_r));
+            const int   ymin = max(1, (int)floorf(y - ext_r));
+            const int   xmax = min(width - 2, (int)floorf(x + ext_r) + 1);
+            const int   ymax = min(height - 2, (int)floorf(y + ext_r) + 1);
+            const int   wx = xmax - xmin + 1;
+            const int   hy = ymax - ymin + 1;
+            const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
+
+            for (int i = tid; i < loops; i += 256) {
+                const int   ii = i / wx + ymin;
+                const int   jj = i - (i / wx) * wx + xmin;
+                const float dx = jj - x, dy = ii - y;
+                /* position in cell units relative to the keypoint: cell (ix,iy) is centred
+                 * at (ix-1.5, iy-1.5); n = u - off, dn = n + off = u (s_desc_loop.cu:88-99) */
+                const float u = fmaf(crsbp, dx, srsbp * dy);
+                const float v = fmaf(crsbp, dy, -srsbp * dx);
+                if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
+                    float mod, th;
+                    get_gradiant(mod, th, jj, ii, layer, od.pitch);
+                    const float ww = expf(-0.125f * (u * u + v * v));
+
+                    th -= ang;
+                    th += (th < 0.0f ? F_PI2 : 0.0f);
+                    th -= (th >= F_PI2 ? F_PI2 : 0.0f);
+                    const float tth = th * M_4RPI;
+                    const int   fo0 = (int)floorf(tth);
+                    const float do0 = tth - fo0;
+                    const int   b0 = fo0 & 7, b1 = (fo0 + 1) & 7;
+
+                    const float tu = u + 1.5f, tv = v + 1.5f; /* cell centres at 0..3 */
+                    const int   cx0 = (int)floorf(tu), cy0 = (int)floorf(tv);
+#pragma unroll
+                    for (int cy = 0; cy < 2; cy++) {
+                        const int   iy = cy0 + cy;
+                        const float ny = fabsf(tv - iy);
+                        if (iy < 0 || iy > 3 || !(ny < 1.0f)) continue;
+#pragma unroll
+                        for (int cxi = 0; cxi < 2; cxi++) {
+                            const int   ix = cx0 + cxi;
+                            const float nx = fabsf(tu - ix);
+                            if (ix < 0 || ix > 3 || !(nx < 1.0f)) continue;
+                            const float wgt = ww * (1.0f - nx) * (1.0f - ny) * mod;
+                            float*      cell = &s_hist[((iy << 2) + ix) << 3];
+                            atomicAdd(&cell[b0], (1.0f - do0) * wgt);
+                            atomicAdd(&cell[b1], do0 * wgt);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134) */
+        float val = (tid < 128) ? s_hist[tid] : 0.0f;
+        if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
+            float sum = val;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            if (lane == 0) s_red[wave] = sum;
+            __syncthreads();
+            sum = s_red[0] + s_red[1];
+            val = scalbnf(sqrtf(val / sum), sc.norm_multi);
+        } else {
+            float sq = val * val;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            if (lane == 0) s_red[wave] = sq;
+            __syncthreads();
+            const float norm = sqrtf(s_red[0] + s_red[1]);
+            __syncthreads();
+            val = fminf(val, 0.2f * norm);
+            sq = val * val;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            if (lane == 0) s_red[wave] = sq;
+            __syncthreads();
+            float rn = 1.0f / sqrtf(s_red[0] + s_red[1]);
+            rn = scalbnf(rn, sc.norm_multi);
+            val = val * rn;
+        }
+        if (tid < 128) desc[(size_t)d * 128 + tid] = val;
+        __syncthreads();
+    }
+}
+
+/* --------------------------------------------------------------- features */
+
+__global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __restrict__ ct,
+                                              const Ext* __restrict__ ext, popsift_hip_feature* __restrict__ feats,
+                                              int desc_cap)
+{
+    const int total = ct->ext_total;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        const Ext           e = ext[g];
+        popsift_hip_feature f;
+        const float         scl = powf(2.0f, (float)(e.octave - sc.up_fac_int));
+        f.debug_octave = e.octave;
+        f.xpos = e.xpos * scl;
+        f.ypos = e.ypos * scl;
+        f.sigma = e.sigma * scl;
+        f.num_ori = e.num_ori;
+#pragma unroll
+        for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) {
+            const bool on = k < e.num_ori && e.idx_ori + k < desc_cap;
+            f.desc_idx[k] = on ? e.idx_ori + k : -1;
+            f.orientation[k] = (k < e.num_ori) ? e.orientation[k] : 0.0f;
+        }
+        feats[g] = f;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_orientation(const PyrDesc& pd, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
+                              Ext* ext, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_orientation, dim3(blocks), dim3(256), 0, s, pd, sc, ct, iext, ext);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan(const PyrDesc& pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* map, int desc_cap,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, pd, sc, ct, ext, map, desc_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_descriptors(const PyrDesc& pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
+                              const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, sc, ct, ext, map, desc, desc_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep(const SiftConsts& sc, const Counters* ct, const Ext* ext, popsift_hip_feature* feats,
+                       int desc_cap, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prep, dim3(blocks), dim3(256), 0, s, sc, ct, ext, feats, desc_cap);
+    return hipGetLastError();
+}
+
+}  // namespace popsift_hip

@@ -1,0 +1,266 @@
+/*
+ * pyramid.hip -- Gaussian scale-space + DoG for gfx950 (wave64, LDS-tiled).
+ *
+ * Replaces, per level, the reference's separate passes
+ *   gauss::normalizedSource::horiz  (s_pyramid_build_ra.cu:17-55)
+ *   gauss::absoluteSource::horiz    (s_pyramid_build_aa.cu:17-52)
+ *   gauss::absoluteSource::vert     (s_pyramid_build_aa.cu:55-91)
+ *   gauss::make_dog                 (s_pyramid_build.cu:74-92)
+ *   gauss::get_by_2_pick_every_second (s_pyramid_build.cu:50-71)
+ * by ONE kernel per level: stage the source tile (+halo) in LDS, horizontal
+ * pass LDS->LDS with a register window (4 outputs / lane, ds_read_b128),
+ * vertical pass from LDS with a register window (16 outputs / lane), write the
+ * Gaussian plane and the DoG plane.  No intermediate plane ever reaches HBM.
+ *
+ * Arithmetic is kept in the reference's order (outermost tap first, explicit
+ * fmaf exactly where "out += a * g" appears) and compiled with
+ * -ffp-contract=off, so planes are bit-identical to the CPU oracle.  A kernel
+ * instantiated for HALO >= span-1 runs shorter filters with zero-padded taps:
+ * fmaf(v, 0, out) == out for finite v, so the result does not change.
+ */
+#include <hip/hip_runtime.h>
+
+#include "sift_types.h"
+#include "kernels.h"
+
+namespace popsift_hip {
+
+namespace {
+
+constexpr int TW = 128; /* tile width  (outputs) */
+constexpr int TH = 32;  /* tile height (outputs) */
+constexpr int NT = 256; /* threads per workgroup */
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* One axis of a CUDA linear-filter fetch at normalised coordinate r
+ * (s_image.cu:140-169: normalised coords, clamp, linear, 1.8 fixed-point weight). */
+__device__ __forceinline__ void lin_coord(float r, int n, int& i0, float& alpha)
+{
+    const float xb = r * (float)n - 0.5f;
+    const float fl = floorf(xb);
+    float       a = xb - fl;
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    i0 = (int)fl;
+    alpha = a;
+}
+
+template <typename T>
+__device__ __forceinline__ float texel(const T* img, int w, int h, int pitch, int x, int y);
+template <>
+__device__ __forceinline__ float texel<uint8_t>(const uint8_t* img, int w, int h, int pitch, int x, int y)
+{
+    x = clampi(x, 0, w - 1);
+    y = clampi(y, 0, h - 1);
+    return (float)img[(size_t)y * pitch + x] / 255.0f;
+}
+template <>
+__device__ __forceinline__ float texel<float>(const float* img, int w, int h, int pitch, int x, int y)
+{
+    x = clampi(x, 0, w - 1);
+    y = clampi(y, 0, h - 1);
+    return img[(size_t)y * pitch + x];
+}
+
+/* XCD-aware tile order: blocks b and b+8 share an XCD (and its 4 MiB L2), so
+ * give each XCD a contiguous run of tiles -- neighbouring tiles share halos. */
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+/*
+ * MODE 0: level l >= 1 from plane l-1 (centre tap first in the H pass, DoG out)
+ * MODE 1: octave 0 level 0 from the u8 input image (bilinear upscale on the fly)
+ * MODE 2: octave 0 level 0 from the f32 input image
+ */
+template <int HALO, int MODE>
+__global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
+{
+    constexpr int HP = (HALO + 3) & ~3;   /* left/right halo, padded to 16 B   */
+    constexpr int SW = TW + 2 * HP;       /* LDS row pitch of the source tile  */
+    constexpr int SR = TH + 2 * HALO;     /* rows staged                       */
+    constexpr int WIN = 4 + 2 * HP;       /* H-pass register window (floats)   */
+    constexpr int VO = TH / 2;            /* V-pass outputs per lane           */
+    constexpr int VWIN = VO + 2 * HALO;
+
+    __shared__ __attribute__((aligned(16))) float s_src[SR * SW];
+    __shared__ __attribute__((aligned(16))) float s_hb[SR * TW];
+
+    const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int tx0 = (tile % a.tiles_x) * TW;
+    const int ty0 = (tile / a.tiles_x) * TH;
+    const int tid = threadIdx.x;
+    const int w = a.w, h = a.h, pitch = a.pitch;
+
+    /* ---- phase 1: stage source tile (+halo) with clamp addressing -------- */
+    if (MODE == 0) {
+        const float* __restrict__ src = a.src;
+        for (int idx = tid; idx < SR * SW; idx += NT) {
+            const int r = idx / SW, c = idx - r * SW;
+            const int gx = clampi(tx0 + c - HP, 0, w - 1);
+            const int gy = clampi(ty0 + r - HALO, 0, h - 1);
+            s_src[idx] = src[(size_t)gy * pitch + gx];
+        }
+    } else {
+        /* s_pyramid_build_ra.cu:38-39: read_x = (x + shift) / dst_w (normalised) */
+        for (int idx = tid; idx < SR * SW; idx += NT) {
+            const int   r = idx / SW, c = idx - r * SW;
+            const int   X = tx0 + c - HP;
+            const int   Y = clampi(ty0 + r - HALO, 0, h - 1);
+            const float read_x = ((float)X + a.shift) / (float)w;
+            const float read_y = ((float)Y + a.shift) / (float)h;
+            int         ix, iy;
+            float       fa, fb;
+            lin_coord(read_x, a.in_w, ix, fa);
+            lin_coord(read_y, a.in_h, iy, fb);
+            float t00, t10, t01, t11;
+            if (MODE == 1) {
+                const uint8_t* img = (const uint8_t*)a.in;
+                t00 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix, iy);
+                t10 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy);
+                t01 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix, iy + 1);
+                t11 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy + 1);
+            } else {
+                const float* img = (const float*)a.in;
+                t00 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix, iy);
+                t10 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy);
+                t01 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix, iy + 1);
+                t11 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy + 1);
+            }
+            const float top = (1.0f - fa) * t00 + fa * t10;
+            const float bot = (1.0f - fa) * t01 + fa * t11;
+            s_src[idx] = (1.0f - fb) * top + fb * bot;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 2: horizontal pass, 4 outputs per lane -------------------- */
+    {
+        const int lx = (tid & 31) * 4; /* first output column of this lane */
+        for (int r = tid >> 5; r < SR; r += NT / 32) {
+            float         win[WIN];
+            const float4* p = reinterpret_cast<const float4*>(&s_src[r * SW + lx]);
+#pragma unroll
+            for (int j = 0; j < WIN / 4; j++) {
+                const float4 v = p[j];
+                win[4 * j + 0] = v.x;
+                win[4 * j + 1] = v.y;
+                win[4 * j + 2] = v.z;
+                win[4 * j + 3] = v.w;
+            }
+            float out[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int cpos = HP + o; /* centre of output o inside win[] */
+                float     acc;
+                if (MODE == 0) {
+                    acc = win[cpos] * a.taps.g[0];
+#pragma unroll
+                    for (int k = HALO; k > 0; k--)
+                        acc = fmaf(win[cpos - k] + win[cpos + k], a.taps.g[k], acc);
+                } else {
+                    acc = 0.0f;
+#pragma unroll
+                    for (int k = HALO; k > 0; k--)
+                        acc = fmaf(win[cpos - k] + win[cpos + k], a.taps.g[k], acc);
+                    acc = fmaf(win[cpos], a.taps.g[0], acc);
+                    acc = acc * 255.0f;
+                }
+                out[o] = acc;
+            }
+            *reinterpret_cast<float4*>(&s_hb[r * TW + lx]) = make_float4(out[0], out[1], out[2], out[3]);
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 3: vertical pass, VO outputs per lane, + DoG -------------- */
+    {
+        const int cx = tid & (TW - 1);
+        const int r0 = (tid / TW) * VO; /* first output row (tile-relative) */
+        float     win[VWIN];
+#pragma unroll
+        for (int j = 0; j < VWIN; j++) win[j] = s_hb[(r0 + j) * TW + cx];
+        const int gx = tx0 + cx;
+#pragma unroll
+        for (int o = 0; o < VO; o++) {
+            const int cpos = HALO + o;
+            float     acc = 0.0f;
+#pragma unroll
+            for (int k = HALO; k > 0; k--) {
+                acc = fmaf(win[cpos - k], a.taps.g[k], acc);
+                acc = fmaf(win[cpos + k], a.taps.g[k], acc);
+            }
+            acc = fmaf(win[cpos], a.taps.g[0], acc);
+            const int gy = ty0 + r0 + o;
+            if (gx < w && gy < h) {
+                a.dst[(size_t)gy * pitch + gx] = acc;
+                if (MODE == 0)
+                    a.dog[(size_t)gy * pitch + gx] = acc - s_src[(r0 + o + HALO) * SW + cx + HP];
+            }
+        }
+    }
+}
+
+/* get_by_2_pick_every_second (s_pyramid_build.cu:50-71) */
+__global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src, int sw, int sh, int spitch,
+                                                  float* __restrict__ dst, int dw, int dh, int dpitch)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const int rx = min(x << 1, sw - 1);
+    const int ry = min(y << 1, sh - 1);
+    dst[(size_t)y * dpitch + x] = src[(size_t)ry * spitch + rx];
+}
+
+template <int MODE>
+hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
+{
+    const dim3 grid(a.tiles_x * a.tiles_y), block(NT);
+#define PS_CASE(H)                                               \
+    if (halo <= H) {                                             \
+        hipLaunchKernelGGL((k_blur_tile<H, MODE>), grid, block, 0, s, a); \
+        return hipGetLastError();                                \
+    }
+    PS_CASE(4)
+    PS_CASE(5)
+    PS_CASE(6)
+    PS_CASE(7)
+    PS_CASE(8)
+    PS_CASE(10)
+    PS_CASE(13)
+    PS_CASE(16)
+    PS_CASE(22)
+    PS_CASE(30)
+#undef PS_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+int blur_tile_w() { return TW; }
+int blur_tile_h() { return TH; }
+
+hipError_t launch_blur(const BlurArgs& a, int mode, int span, hipStream_t s)
+{
+    const int halo = span - 1;
+    if (halo < 0 || halo > 30) return hipErrorInvalidValue;
+    switch (mode) {
+    case 0: return launch_blur_mode<0>(a, halo, s);
+    case 1: return launch_blur_mode<1>(a, halo, s);
+    case 2: return launch_blur_mode<2>(a, halo, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* dst, int dw, int dh,
+                           int dpitch, hipStream_t s)
+{
+    const dim3 grid((dw + 63) / 64, (dh + 3) / 4), block(256);
+    hipLaunchKernelGGL(k_decimate, grid, block, 0, s, src, sw, sh, spitch, dst, dw, dh, dpitch);
+    return hipGetLastError();
+}
+
+}  // namespace popsift_hip

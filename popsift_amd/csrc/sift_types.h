@@ -1,0 +1,71 @@
+/*
+ * sift_types.h -- device/host shared plain structs of libpopsift_hip.
+ * Data layout in HBM (see DESIGN.md "Data layout"):
+ *   - every Gaussian / DoG plane is a row-major float plane, row pitch padded
+ *     to 64 floats (256 B), all planes of a context carved from one arena;
+ *   - extrema / features / descriptors are flat arrays sized by max_extrema.
+ */
+#pragma once
+#include <stdint.h>
+
+#include "../../include/popsift_hip.h"
+
+#define PS_MAX_OCT POPSIFT_HIP_MAX_OCTAVES
+#define PS_MAX_PLANES (POPSIFT_HIP_MAX_LEVELS + 3)
+#define PS_GA POPSIFT_HIP_GAUSS_ALIGN
+#define PS_ORI_NBINS 36
+
+/* One octave: planes are at base + level * plane_stride (floats). */
+struct OctDesc {
+    float*  data;         /* L Gaussian planes   */
+    float*  dog;          /* L-1 DoG planes      */
+    int64_t plane_stride; /* floats per plane = pitch * h */
+    int     w, h, pitch;
+    int     tile_begin;   /* first block of this octave in whole-pyramid launches */
+};
+
+struct PyrDesc {
+    int     n_oct;
+    int     levels; /* DoG search levels */
+    int     L;      /* levels + 3        */
+    int     total_tiles;
+    OctDesc o[PS_MAX_OCT];
+};
+
+/* sift_constants.h:56-67 ConstInfo (scalar part) + mode switches */
+struct SiftConsts {
+    float sigma0, sigma_k, edge_limit, threshold;
+    int   max_extrema, norm_multi, norm_mode, sift_mode;
+    int   grid_size;
+    int   up_fac_int; /* prep_features(Descriptor*, int up_fac): truncated, sift_pyramid.cu:250 */
+};
+
+/* sift_extremum.h:24-33 InitialExtremum (without the grid-filter bookkeeping) */
+struct InitExt {
+    float xpos, ypos;
+    int   lpos;
+    float sigma;
+    int   cell;
+};
+
+/* sift_extremum.h:40-51 Extremum */
+struct Ext {
+    float xpos, ypos;
+    int   lpos;
+    float sigma;
+    int   octave;
+    int   num_ori;
+    int   idx_ori;
+    float orientation[POPSIFT_HIP_ORI_MAX];
+};
+
+/* sift_pyramid.h:22-37 ExtremaCounters, device resident */
+struct Counters {
+    int ext_ct[PS_MAX_OCT];
+    int ori_ct[PS_MAX_OCT];
+    int ext_ps[PS_MAX_OCT];
+    int ori_ps[PS_MAX_OCT];
+    int ext_total;
+    int ori_total;
+    int pad[2];
+};

@@ -74,6 +74,10 @@ struct popsift_hip_ctx {
     int      desc_cap = 0;
     Counters* d_ct = nullptr;
     Counters* h_ct = nullptr; /* pinned */
+    PyrDesc*  d_pd = nullptr; /* device copy of pd (kernels index octaves dynamically) */
+    PyrDesc*  h_pd = nullptr; /* pinned staging for d_pd */
+    int2*     d_cand = nullptr;
+    int       cand_cap = 0;
 
     /* profiling */
     int                    profile = 0;
@@ -199,6 +203,17 @@ int ensure_desc_cap(popsift_hip_ctx* c, int need)
     return 0;
 }
 
+int ensure_cand_cap(popsift_hip_ctx* c, int need)
+{
+    if (need <= c->cand_cap) return 0;
+    if (c->d_cand) HIP_TRY(c, hipFree(c->d_cand));
+    c->d_cand = nullptr;
+    c->cand_cap = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_cand, (size_t)need * sizeof(int2)));
+    c->cand_cap = need;
+    return 0;
+}
+
 /* Pyramid::Pyramid / resetDimensions: sizes for this image, grow-only arena */
 int prepare_geometry(popsift_hip_ctx* c, int w, int h)
 {
@@ -206,6 +221,8 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     plan_dims(c, w, h, c->frozen_octaves, &n_oct, &bw, &bh);
     c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */
     if (bw < 1 || bh < 1) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image is empty");
+    /* candidates pack (x, y) into 16 bits each; the reference's Plane2D uses short dims too (plane_2d.h:257) */
+    if (bw > 32767 || bh > 32767) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image exceeds 32767 pixels per side");
 
     PyrDesc& pd = c->pd;
     memset(&pd, 0, sizeof(pd));
@@ -221,8 +238,7 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
         od.pitch = (ow + PITCH_ALIGN - 1) / PITCH_ALIGN * PITCH_ALIGN;
         od.plane_stride = (int64_t)od.pitch * oh;
         od.tile_begin = tiles;
-        tiles += ((ow + extrema_tile_w() - 1) / extrema_tile_w()) * ((oh + extrema_tile_h() - 1) / extrema_tile_h()) *
-                 c->levels;
+        tiles += extrema_units(ow, oh);
         total += (size_t)od.plane_stride * (size_t)(2 * c->L - 1);
         ow = (int)ceilf(ow / 2.0f); /* sift_pyramid.cu:132-133 */
         oh = (int)ceilf(oh / 2.0f);
@@ -248,6 +264,10 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
         return rc;
+    if (int rc = ensure_cand_cap(c, 1 << 20)) return rc;
+    /* the stream is idle here (submit drains the previous image first), so h_pd is free to reuse */
+    *c->h_pd = c->pd;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pd, c->h_pd, sizeof(PyrDesc), hipMemcpyHostToDevice, c->stream));
     c->in_w = w;
     c->in_h = h;
     c->rep.num_octaves = n_oct;
@@ -332,10 +352,10 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
-    HIP_TRY(c, launch_extrema(c->pd, c->sc, c->d_ct, c->d_iext, c->stream));
-    HIP_TRY(c, launch_orientation(c->pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 2048, c->stream));
-    HIP_TRY(c, launch_scan(c->pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->desc_cap, c->stream));
-    HIP_TRY(c, launch_descriptors(c->pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 4096,
+    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_iext, c->stream));
+    HIP_TRY(c, launch_orientation(c->d_pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 2048, c->stream));
+    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->desc_cap, c->stream));
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 2048,
                                   c->stream));
     HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
@@ -383,10 +403,15 @@ int finish(popsift_hip_ctx* c)
     HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->h_ct->ori_total <= c->desc_cap) break;
-        /* more descriptors than the buffer holds (the reference reallocates between stages,
-         * sift_pyramid.cu:179-209): grow and redo the keypoint stages of this image */
-        if (int rc = ensure_desc_cap(c, c->h_ct->ori_total + c->h_ct->ori_total / 8 + 1024)) return rc;
+        const bool desc_short = c->h_ct->ori_total > c->desc_cap;
+        const bool cand_short = c->h_ct->pad[0] > c->cand_cap;
+        if (!desc_short && !cand_short) break;
+        /* more candidates / descriptors than the buffers hold (the reference reallocates between
+         * stages, sift_pyramid.cu:179-209): grow and redo the keypoint stages of this image */
+        if (desc_short)
+            if (int rc = ensure_desc_cap(c, c->h_ct->ori_total + c->h_ct->ori_total / 8 + 1024)) return rc;
+        if (cand_short)
+            if (int rc = ensure_cand_cap(c, c->h_ct->pad[0] + c->h_ct->pad[0] / 8 + 1024)) return rc;
         if (int rc = enqueue_keypoint_stages(c)) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     }
@@ -514,6 +539,8 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
         HIP_TRY(c, hipEventCreate(&c->ev_end));
         HIP_TRY(c, hipMalloc((void**)&c->d_ct, sizeof(Counters)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_pd, sizeof(PyrDesc)));
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_pd, sizeof(PyrDesc), hipHostMallocDefault));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_ct, sizeof(Counters), hipHostMallocDefault));
         memset(c->h_ct, 0, sizeof(Counters));
         return 0;
@@ -545,6 +572,9 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->d_ct) (void)hipFree(c->d_ct);
+    if (c->d_pd) (void)hipFree(c->d_pd);
+    if (c->h_pd) (void)hipHostFree(c->h_pd);
+    if (c->d_cand) (void)hipFree(c->d_cand);
     if (c->h_ct) (void)hipHostFree(c->h_ct);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

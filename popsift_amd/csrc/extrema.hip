@@ -23,8 +23,6 @@
 namespace popsift_hip {
 namespace {
 
-constexpr int ETW = 64; /* pixels per block row  */
-constexpr int ETH = 16; /* rows per block        */
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -251,99 +249,226 @@ __device__ bool refine(const DogView& dog, const SiftConsts& sc, int x, int y, i
     return true;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_extrema(PyrDesc pd, SiftConsts sc, Counters* __restrict__ ct,
-                                                 InitExt* __restrict__ iext)
+/*
+ * Detection: every DoG value is read exactly once.  One wave owns a strip of 62
+ * candidate columns (lanes 1..62; lanes 0 and 63 only supply neighbours) and
+ * marches down DET_RH rows.  For each of the 5 planes a row is reduced to
+ * max3/min3 over (left, self, right) with two lane shifts; three consecutive
+ * rows of these give the 3x3 neighbourhood extremes of the planes above and
+ * below, and (with the centre excluded) of the own plane -- the strict 26-
+ * neighbour test of s_extrema.cu:56-120 without any divergent load.
+ */
+constexpr int DET_W = 62;
+constexpr int DET_RH = 32;
+constexpr int DET_Q = 1024; /* per-wave candidate queue (entries) */
+
+template <int NP>
+struct RowRed {
+    float mx[NP], mn[NP];
+};
+
+/* LEVELS = DoG search levels; NP = LEVELS + 2 DoG planes */
+template <int MODE, int LEVELS>
+__global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                Counters* __restrict__ ct, int2* __restrict__ cand, int cand_cap)
 {
-    /* block -> (octave, level, tile) */
-    int o = 0;
-    while (o + 1 < pd.n_oct && (int)blockIdx.x >= pd.o[o + 1].tile_begin) o++;
-    const OctDesc& od = pd.o[o];
-    const int      tiles_x = (od.w + ETW - 1) / ETW;
-    const int      tiles_y = (od.h + ETH - 1) / ETH;
-    int            t = blockIdx.x - od.tile_begin;
-    const int      level = t / (tiles_x * tiles_y) + 1;
-    t -= (level - 1) * tiles_x * tiles_y;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= pdp->total_tiles) return;
+    const int n_oct = pdp->n_oct;
+    int       o = 0;
+    while (o + 1 < n_oct && unit >= pdp->o[o + 1].tile_begin) o++;
+    const OctDesc od = pdp->o[o];
+    const int      w = od.w, h = od.h;
+    const int      strips = (w - 2 + DET_W - 1) / DET_W;
+    const int      u = unit - od.tile_begin;
+    const int      cy = u / strips, sx = u - cy * strips;
+    const int      x = sx * DET_W + lane;
+    const int      xc = min(x, w - 1);
+    const int      yb = 1 + cy * DET_RH;
+    const int      ye = min(yb + DET_RH - 1, h - 2);
+    if (strips <= 0 || yb > ye) return;
 
-    DogView dog;
-    dog.base = od.dog;
-    dog.ps = od.plane_stride;
-    dog.w = od.w;
-    dog.h = od.h;
-    dog.pitch = od.pitch;
-    dog.nl = pd.L - 1;
-    const int maxlevel = pd.L - 1; /* s_extrema.cu:608: _levels-1 */
-
-    const int   lane = threadIdx.x & 63;
-    const int   x = tx * ETW + lane;
     const float first_thr = (MODE == POPSIFT_HIP_SIFT_OPENCV)   ? floorf(sc.threshold)
                             : (MODE == POPSIFT_HIP_SIFT_VLFEAT) ? 0.8f * 2.0f * sc.threshold
                                                                 : 1.6f * sc.threshold;
-    InitExt* out = iext + (size_t)o * sc.max_extrema;
+    bool lane_ok = (lane >= 1 && lane <= DET_W && x <= w - 2);
+    if (MODE == POPSIFT_HIP_SIFT_OPENCV) lane_ok = lane_ok && (x >= 5 && x < w - 5);
 
-    for (int ry = (threadIdx.x >> 6); ry < ETH; ry += 4) {
-        const int y = ty * ETH + ry;
-        bool      found = false;
-        InitExt   ec;
-        /* the reference scans x,y >= 1; pixels on the last row/column compare
-         * against their own clamped copy and can never be strict extrema */
-        bool cand = (x >= 1 && y >= 1 && x <= od.w - 2 && y <= od.h - 2);
-        if (MODE == POPSIFT_HIP_SIFT_OPENCV)
-            cand = cand && !(x < 5 || y < 5 || x >= od.w - 5 || y >= od.h - 5);
-        if (cand) {
-            const float val = dog.raw(x, y, level);
-            if (fabsf(val) >= first_thr) {
-                /* strict max or strict min of the 26 neighbours (s_extrema.cu:56-120) */
-                bool gt = true, lt = true;
+    /* Candidates are staged per wave in LDS and flushed with ONE global atomicAdd
+     * per ~DET_Q entries: a returning atomic on a single hot counter saturates
+     * at ~90 per microsecond (MI355X_MICROARCH.md "dequeue"), which made a
+     * per-row atomic the whole cost of this kernel. */
+    __shared__ int2 s_queue[4][DET_Q];
+    int2*           queue = s_queue[threadIdx.x >> 6];
+    int             n_buf = 0;
+    auto            flush = [&](int n) -> int {
+        if (n == 0) return 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int basei = 0;
+        if (lane == 0) basei = atomicAdd(&ct->pad[0], n);
+        basei = __shfl(basei, 0);
+        for (int i = lane; i < n; i += 64)
+            if (basei + i < cand_cap) cand[basei + i] = queue[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return 0;
+    };
+
+    constexpr int NP = LEVELS + 2;
+    const float*  base = od.dog + xc;
+    RowRed<NP>    A, B, C;
+    float         vB[NP], smx[NP], smn[NP];
+
+    auto load_row = [&](int y, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
+        const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
-                for (int dz = -1; dz <= 1; dz++)
+        for (int z = 0; z < NP; z++) {
+            const float c = p[z * od.plane_stride];
+            const float l = __shfl_up(c, 1);
+            const float r = __shfl_down(c, 1);
+            v[z] = c;
+            sx_[z] = fmaxf(l, r);
+            sn_[z] = fminf(l, r);
+            R.mx[z] = fmaxf(sx_[z], c);
+            R.mn[z] = fminf(sn_[z], c);
+        }
+    };
+    {
+        float tv[NP], ts[NP], tn[NP];
+        load_row(yb - 1, A, tv, ts, tn);
+        load_row(yb, B, vB, smx, smn);
+    }
+    for (int y = yb; y <= ye; y++) {
+        float vC[NP], cmx[NP], cmn[NP];
+        load_row(y + 1, C, vC, cmx, cmn);
+        bool row_ok = lane_ok;
+        if (MODE == POPSIFT_HIP_SIFT_OPENCV) row_ok = row_ok && (y >= 5 && y < h - 5);
+        /* full 3x3 extremes of every plane (centre column included) */
+        float fmx[NP], fmn[NP];
 #pragma unroll
-                    for (int dy = -1; dy <= 1; dy++)
+        for (int z = 0; z < NP; z++) {
+            fmx[z] = fmaxf(fmaxf(A.mx[z], B.mx[z]), C.mx[z]);
+            fmn[z] = fminf(fminf(A.mn[z], B.mn[z]), C.mn[z]);
+        }
 #pragma unroll
-                        for (int dx = -1; dx <= 1; dx++) {
-                            if (dx == 0 && dy == 0 && dz == 0) continue;
-                            if (gt || lt) {
-                                const float f = dog.raw(x + dx, y + dy, level + dz);
-                                gt = gt && (val > f);
-                                lt = lt && (val < f);
-                            }
-                        }
-                if (gt || lt) found = refine<MODE>(dog, sc, x, y, level, val, maxlevel, ec);
+        for (int z = 1; z <= LEVELS; z++) {
+            const float v = vB[z];
+            const float omx = fmaxf(fmaxf(A.mx[z], smx[z]), C.mx[z]); /* own plane, centre excluded */
+            const float omn = fminf(fminf(A.mn[z], smn[z]), C.mn[z]);
+            const float nmax = fmaxf(fmaxf(fmx[z - 1], fmx[z + 1]), omx);
+            const float nmin = fminf(fminf(fmn[z - 1], fmn[z + 1]), omn);
+            const bool  hit = row_ok && (fabsf(v) >= first_thr) && (v > nmax || v < nmin);
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                /* stage in the wave's LDS queue; n_buf is wave-uniform */
+                if (hit) queue[n_buf + __popcll(mask & ((1ull << lane) - 1ull))] = make_int2(x | (y << 16), z | (o << 8));
+                n_buf += __popcll(mask);
             }
         }
-        /* wave64 compaction (replaces extrema_count, s_extrema.cu:22-44) */
-        const unsigned long long mask = __ballot(found);
-        if (mask) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&ct->ext_ct[o], __popcll(mask));
-            base = __shfl(base, 0);
-            if (found) {
+        if (n_buf > DET_Q - 64 * LEVELS) n_buf = flush(n_buf);
+        A = B;
+        B = C;
+#pragma unroll
+        for (int z = 0; z < NP; z++) {
+            vB[z] = vC[z];
+            smx[z] = cmx[z];
+            smn[z] = cmn[z];
+        }
+    }
+    flush(n_buf);
+}
+
+/* Refinement of the compacted candidates: one lane per candidate, dense waves. */
+template <int MODE>
+__global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                Counters* __restrict__ ct, const int2* __restrict__ cand,
+                                                int cand_cap, InitExt* __restrict__ iext)
+{
+    const int lane = threadIdx.x & 63;
+    const int L = pdp->L;
+    const int total = min(ct->pad[0], cand_cap);
+    /* wave-uniform trip count so that __ballot sees whole waves */
+    for (int i0 = (blockIdx.x * 256 + (threadIdx.x & ~63)); i0 < total; i0 += gridDim.x * 256) {
+        const int i = i0 + lane;
+        bool      found = false;
+        InitExt   ec;
+        int       o = 0;
+        if (i < total) {
+            const int2 cd = cand[i];
+            const int  x = cd.x & 0xffff, y = cd.x >> 16, level = cd.y & 0xff;
+            o = cd.y >> 8;
+            const OctDesc* od = &pdp->o[o];
+            DogView        dog;
+            dog.base = od->dog;
+            dog.ps = od->plane_stride;
+            dog.w = od->w;
+            dog.h = od->h;
+            dog.pitch = od->pitch;
+            dog.nl = L - 1;
+            const float val = dog.raw(x, y, level);
+            found = refine<MODE>(dog, sc, x, y, level, val, L - 1, ec);
+        }
+        /* wave64 compaction per octave (replaces extrema_count, s_extrema.cu:22-44) */
+        unsigned long long todo = __ballot(found);
+        while (todo) {
+            const int                leader = __ffsll((long long)todo) - 1;
+            const int                lo = __shfl(o, leader);
+            const unsigned long long mask = __ballot(found && o == lo);
+            int                      base = 0;
+            if (lane == leader) base = atomicAdd(&ct->ext_ct[lo], __popcll(mask));
+            base = __shfl(base, leader);
+            if (found && o == lo) {
                 const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (idx < sc.max_extrema) out[idx] = ec;
+                if (idx < sc.max_extrema) iext[(size_t)lo * sc.max_extrema + idx] = ec;
             }
+            todo &= ~mask;
         }
     }
 }
 
 }  // namespace
 
-int extrema_tile_w() { return ETW; }
-int extrema_tile_h() { return ETH; }
+int extrema_units(int w, int h)
+{
+    if (w < 3 || h < 3) return 0;
+    return ((w - 2 + DET_W - 1) / DET_W) * ((h - 2 + DET_RH - 1) / DET_RH);
+}
 
-hipError_t launch_extrema(const PyrDesc& pd, const SiftConsts& sc, Counters* ct, InitExt* iext, hipStream_t s)
+template <int MODE>
+static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, int2* cand,
+                          int cand_cap, hipStream_t s)
+{
+    const dim3 grid((pd.total_tiles + 3) / 4), block(256);
+    switch (pd.levels) {
+#define PS_LV(N)                                                                                   \
+    case N:                                                                                        \
+        hipLaunchKernelGGL((k_detect<MODE, N>), grid, block, 0, s, d_pd, sc, ct, cand, cand_cap); \
+        break;
+        PS_LV(2) PS_LV(3) PS_LV(4) PS_LV(5) PS_LV(6) PS_LV(7) PS_LV(8) PS_LV(9)
+#undef PS_LV
+    }
+}
+
+hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, int2* cand,
+                          int cand_cap, InitExt* iext, hipStream_t s)
 {
     if (pd.total_tiles <= 0) return hipSuccess;
-    const dim3 grid(pd.total_tiles), block(256);
+    if (pd.levels < 2 || pd.levels > 9) return hipErrorInvalidValue;
+    const dim3 block(256), rgrid(1024);
     switch (sc.sift_mode) {
     case POPSIFT_HIP_SIFT_OPENCV:
-        hipLaunchKernelGGL((k_extrema<POPSIFT_HIP_SIFT_OPENCV>), grid, block, 0, s, pd, sc, ct, iext);
+        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, sc, ct, cand, cand_cap, s);
+        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV>), rgrid, block, 0, s, d_pd, sc, ct, cand, cand_cap, iext);
         break;
     case POPSIFT_HIP_SIFT_VLFEAT:
-        hipLaunchKernelGGL((k_extrema<POPSIFT_HIP_SIFT_VLFEAT>), grid, block, 0, s, pd, sc, ct, iext);
+        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, sc, ct, cand, cand_cap, s);
+        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT>), rgrid, block, 0, s, d_pd, sc, ct, cand, cand_cap, iext);
         break;
     default:
-        hipLaunchKernelGGL((k_extrema<POPSIFT_HIP_SIFT_POPSIFT>), grid, block, 0, s, pd, sc, ct, iext);
+        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, sc, ct, cand, cand_cap, s);
+        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT>), rgrid, block, 0, s, d_pd, sc, ct, cand, cand_cap, iext);
         break;
     }
     return hipGetLastError();

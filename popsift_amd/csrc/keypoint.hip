@@ -27,6 +27,17 @@ constexpr float F_PI2 = 2.0f * 3.14159265358979323846f;
 constexpr float            ORI_WINFACTOR = 1.5f;
 constexpr float            DESC_MAGNIFY = 3.0f;
 
+/*
+ * Histogram accumulation: on gfx950 an LDS float atomic add (ds_add_f32) costs
+ * ~200 cycles per wave instruction whatever the address pattern, an integer one
+ * ~6 (tools/ubench/lds_atomic.hip).  Bins are therefore 64-bit fixed point
+ * (2^-32 resolution, exact and order-independent sums => bit-reproducible
+ * histograms, unlike the reference's float atomicAdd, s_orientation.cu:136).
+ */
+typedef unsigned long long fix64;
+__device__ __forceinline__ fix64 to_fix(float w) { return (fix64)(w * 4294967296.0f); }
+__device__ __forceinline__ float from_fix(fix64 v) { return (float)((double)v * (1.0 / 4294967296.0)); }
+
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -57,28 +68,30 @@ __device__ __forceinline__ void get_gradiant(float& grad, float& theta, int x, i
 
 /* ------------------------------------------------------------ orientation */
 
-__global__ __launch_bounds__(256) void k_orientation(PyrDesc pd, SiftConsts sc, const Counters* __restrict__ ct,
+__global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                     const Counters* __restrict__ ct,
                                                      const InitExt* __restrict__ iext, Ext* __restrict__ ext)
 {
-    __shared__ float s_hist[4][PS_ORI_NBINS + 4];
+    const int n_oct = pdp->n_oct, L = pdp->L;
+    __shared__ fix64 s_hist[4][PS_ORI_NBINS + 4];
     const int        wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float*           hist = s_hist[wave];
+    fix64*           hist = s_hist[wave];
 
     __shared__ int ps[PS_MAX_OCT + 1];
-    if (threadIdx.x == 0) ext_prefix(ct, sc, pd.n_oct, ps);
+    if (threadIdx.x == 0) ext_prefix(ct, sc, n_oct, ps);
     __syncthreads();
-    const int total = ps[pd.n_oct];
+    const int total = ps[n_oct];
 
     for (int g = blockIdx.x * 4 + wave; g < total; g += gridDim.x * 4) {
         int o = 0;
-        while (o + 1 < pd.n_oct && g >= ps[o + 1]) o++;
+        while (o + 1 < n_oct && g >= ps[o + 1]) o++;
         const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - ps[o])];
-        const OctDesc& od = pd.o[o];
-        const int      w = od.w, h = od.h;
-        const int      lvl = min(max(ie.lpos, 0), pd.L - 1);
-        const float*   layer = od.data + lvl * od.plane_stride;
+        const OctDesc* od = &pdp->o[o];
+        const int      w = od->w, h = od->h, pitch = od->pitch;
+        const int      lvl = min(max(ie.lpos, 0), L - 1);
+        const float*   layer = od->data + lvl * od->plane_stride;
 
-        if (lane < PS_ORI_NBINS) hist[lane] = 0.0f;
+        if (lane < PS_ORI_NBINS) hist[lane] = 0ull;
         wave_lds_sync();
 
         const float x = ie.xpos, y = ie.ypos, sig = ie.sigma;
@@ -92,21 +105,26 @@ __global__ __launch_bounds__(256) void k_orientation(PyrDesc pd, SiftConsts sc, 
         const int   ymax = min(h - 2, (int)roundf(y) + rad);
         const int   wx = xmax - xmin + 1;
         const int   hy = ymax - ymin + 1;
-        const int   loops = wx * hy;
+        const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
+        const float inv_wx = 1.0f / (float)max(wx, 1);
 
         for (int i = lane; i < loops; i += 64) {
-            const int yy = i / wx + ymin;
-            const int xx = i - (i / wx) * wx + xmin;
-            float     grad, theta;
-            get_gradiant(grad, theta, xx, yy, layer, od.pitch);
+            const int    row = (int)(((float)i + 0.5f) * inv_wx);
+            const int    yy = row + ymin;
+            const int    xx = i - row * wx + xmin;
+            const float* c = layer + (size_t)yy * pitch + xx;
+            const float  gdx = c[1] - c[-1];
+            const float  gdy = c[pitch] - c[-pitch];
+            const float  grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
+            const float  theta = atan2f(gdy, gdx);
             const float dx = xx - x;
             const float dy = yy - y;
             const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
             if (sq_dist <= sq_thres) {
-                const float weight = grad * expf(sq_dist * factor);
+                const float weight = grad * __expf(sq_dist * factor);
                 int         bidx = (int)roundf((float)PS_ORI_NBINS * (theta + F_PI) / F_PI2);
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
-                if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], weight);
+                if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));
             }
         }
         wave_lds_sync();
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(256) void k_orientation(PyrDesc pd, SiftConsts sc, 
         const int bin = lane;
         const int prev = (bin == 0) ? PS_ORI_NBINS - 1 : bin - 1;
         const int next = (bin >= PS_ORI_NBINS - 1) ? 0 : bin + 1;
-        float     hv = (lane < PS_ORI_NBINS) ? hist[lane] : 0.0f;
+        float     hv = (lane < PS_ORI_NBINS) ? from_fix(hist[lane]) : 0.0f;
 #pragma unroll
         for (int pass = 0; pass < 6; pass++) {
             const float hp = __shfl(hv, prev);
@@ -182,9 +200,11 @@ __global__ __launch_bounds__(256) void k_orientation(PyrDesc pd, SiftConsts sc, 
 
 /* ------------------------------------------------------------------- scan */
 
-__global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counters* __restrict__ ct,
-                                               Ext* __restrict__ ext, int* __restrict__ map, int desc_cap)
+__global__ __launch_bounds__(1024) void k_scan(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                               Counters* __restrict__ ct, Ext* __restrict__ ext,
+                                               int* __restrict__ map, int desc_cap)
 {
+    const int n_oct = pdp->n_oct;
     __shared__ int s_wsum[16];
     __shared__ int s_carry;
     __shared__ int s_ps[PS_MAX_OCT + 1];
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counte
     if (tid == 0) {
         int acc = 0;
         for (int o = 0; o < PS_MAX_OCT; o++) {
-            const int c = (o < pd.n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
+            const int c = (o < n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
             ct->ext_ct[o] = c; /* the reference clamps with atomicMin, s_extrema.cu:558 */
             ct->ext_ps[o] = acc;
             s_ps[o] = acc;
@@ -206,11 +226,17 @@ __global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counte
     __syncthreads();
     const int total = s_ps[PS_MAX_OCT];
 
-    for (int base = 0; base < total; base += 1024) {
-        const int  g = base + tid;
-        const bool valid = g < total;
-        const int  self = valid ? ext[g].num_ori : 0;
-        /* inclusive wave64 scan */
+    constexpr int ITEMS = 16; /* consecutive extrema per lane */
+    for (int base = 0; base < total; base += 1024 * ITEMS) {
+        const int g0 = base + tid * ITEMS;
+        int       cnt[ITEMS];
+        int       self = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            cnt[k] = (g0 + k < total) ? ext[g0 + k].num_ori : 0;
+            self += cnt[k];
+        }
+        /* inclusive wave64 scan of the per-lane sums */
         int incl = self;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
@@ -231,14 +257,18 @@ __global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counte
         }
         __syncthreads();
         const int carry = s_carry;
-        const int excl = carry + s_wsum[wave] + incl - self;
-        if (valid) {
-            ext[g].idx_ori = excl;
-            for (int k = 0; k < self; k++)
-                if (excl + k < desc_cap) map[excl + k] = g;
+        int       excl = carry + s_wsum[wave] + incl - self;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            if (g0 + k < total) {
+                ext[g0 + k].idx_ori = excl;
+                for (int q = 0; q < cnt[k]; q++)
+                    if (excl + q < desc_cap) map[excl + q] = g0 + k;
+            }
+            excl += cnt[k];
         }
         __syncthreads();
-        if (tid == 1023) s_carry = excl + self;
+        if (tid == 1023) s_carry = excl;
         __syncthreads();
     }
 
@@ -248,7 +278,7 @@ __global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counte
         int acc = 0;
         for (int o = 0; o < PS_MAX_OCT; o++) {
             int c = 0;
-            if (o < pd.n_oct && ct->ext_ct[o] > 0) {
+            if (o < n_oct && ct->ext_ct[o] > 0) {
                 const int fe = s_ps[o], le = s_ps[o + 1] - 1;
                 c = ext[le].idx_ori + ext[le].num_ori - ext[fe].idx_ori;
             }
@@ -263,36 +293,42 @@ __global__ __launch_bounds__(1024) void k_scan(PyrDesc pd, SiftConsts sc, Counte
 /* ------------------------------------------------------------- descriptor */
 
 /*
- * One workgroup (256 lanes) per (extremum, orientation).  The reference gives
- * every one of the 16 cells its own warp, which re-computes the gradient of
- * each patch pixel for up to four overlapping cells (s_desc_loop.cu:78-122).
- * Here each patch pixel is visited once: its gradient is computed once and
- * its contribution is spread to the (at most) 2x2 cells whose unit square
- * contains it -- the same sample set and weights, a different summation order.
+ * One wave per (extremum, orientation), four per workgroup, no workgroup
+ * barrier.  The reference gives every one of the 16 cells its own warp, which
+ * re-computes the gradient of each patch pixel for up to four overlapping
+ * cells (s_desc_loop.cu:78-122).  Here each patch pixel is visited once: its
+ * gradient is computed once and its contribution is spread to the (at most)
+ * 2x2 cells whose unit square contains it -- the same sample set and weights,
+ * a different summation order.  The 128-bin histogram lives in LDS (per wave),
+ * is normalised in registers and leaves as two coalesced 256 B rows.
  */
-__global__ __launch_bounds__(256) void k_descriptor(PyrDesc pd, SiftConsts sc, const Counters* __restrict__ ct,
-                                                    const Ext* __restrict__ ext, const int* __restrict__ map,
-                                                    float* __restrict__ desc, int desc_cap)
+__global__ __launch_bounds__(256) void k_descriptor(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                    const Counters* __restrict__ ct, const Ext* __restrict__ ext,
+                                                    const int* __restrict__ map, float* __restrict__ desc,
+                                                    int desc_cap)
 {
-    __shared__ float s_hist[128];
-    __shared__ float s_red[4];
-    const int        tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ fix64 s_hist[4][128];
+    const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    fix64*           hist = s_hist[wave];
     const int        total = min(ct->ori_total, desc_cap);
+    const int        L = pdp->L;
     const float      M_4RPI = 4.0f / F_PI;
 
-    for (int d = blockIdx.x; d < total; d += gridDim.x) {
-        const Ext      e = ext[map[d]];
-        const float    ang = e.orientation[min(max(d - e.idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1)];
-        const OctDesc& od = pd.o[e.octave];
-        const int      width = od.w, height = od.h;
-        const int      lvl = min(max(e.lpos, 0), pd.L - 1);
-        const float*   layer = od.data + lvl * od.plane_stride;
+    for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
+        const Ext*     e = ext + map[d];
+        const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
+        const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
+        const float    ang = e->orientation[ko];
+        const OctDesc* od = &pdp->o[e->octave];
+        const int      width = od->w, height = od->h, pitch = od->pitch;
+        const int      lvl = min(max(e->lpos, 0), L - 1);
+        const float*   layer = od->data + lvl * od->plane_stride;
 
-        if (tid < 128) s_hist[tid] = 0.0f;
-        __syncthreads();
+        hist[lane] = 0ull;
+        hist[lane + 64] = 0ull;
+        wave_lds_sync();
 
-        const float x = e.xpos, y = e.ypos;
-        const float SBP = fabsf(DESC_MAGNIFY * e.sigma);
+        const float SBP = fabsf(DESC_MAGNIFY * sigma);
         if (SBP != 0.0f) {
             float sin_t, cos_t;
             sincosf(ang, &sin_t, &cos_t);
@@ -308,19 +344,24 @@ __global__ __launch_bounds__(256) void k_descriptor(PyrDesc pd, SiftConsts sc, c
             const int   wx = xmax - xmin + 1;
             const int   hy = ymax - ymin + 1;
             const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
+            const float inv_wx = 1.0f / (float)max(wx, 1);
 
-            for (int i = tid; i < loops; i += 256) {
-                const int   ii = i / wx + ymin;
-                const int   jj = i - (i / wx) * wx + xmin;
+            for (int i = lane; i < loops; i += 64) {
+                const int   row = (int)(((float)i + 0.5f) * inv_wx);
+                const int   ii = row + ymin;
+                const int   jj = i - row * wx + xmin;
                 const float dx = jj - x, dy = ii - y;
                 /* position in cell units relative to the keypoint: cell (ix,iy) is centred
                  * at (ix-1.5, iy-1.5); n = u - off, dn = n + off = u (s_desc_loop.cu:88-99) */
                 const float u = fmaf(crsbp, dx, srsbp * dy);
                 const float v = fmaf(crsbp, dy, -srsbp * dx);
                 if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
-                    float mod, th;
-                    get_gradiant(mod, th, jj, ii, layer, od.pitch);
-                    const float ww = expf(-0.125f * (u * u + v * v));
+                    const float* c = layer + (size_t)ii * pitch + jj;
+                    const float  gx = c[1] - c[-1];
+                    const float  gy = c[pitch] - c[-pitch];
+                    const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
+                    float        th = atan2f(gy, gx);
+                    const float  ww = __expf(-0.125f * (u * u + v * v));
 
                     th -= ang;
                     th += (th < 0.0f ? F_PI2 : 0.0f);
@@ -332,6 +373,7 @@ __global__ __launch_bounds__(256) void k_descriptor(PyrDesc pd, SiftConsts sc, c
 
                     const float tu = u + 1.5f, tv = v + 1.5f; /* cell centres at 0..3 */
                     const int   cx0 = (int)floorf(tu), cy0 = (int)floorf(tv);
+                    const float wm = ww * mod;
 #pragma unroll
                     for (int cy = 0; cy < 2; cy++) {
                         const int   iy = cy0 + cy;
@@ -342,47 +384,43 @@ __global__ __launch_bounds__(256) void k_descriptor(PyrDesc pd, SiftConsts sc, c
                             const int   ix = cx0 + cxi;
                             const float nx = fabsf(tu - ix);
                             if (ix < 0 || ix > 3 || !(nx < 1.0f)) continue;
-                            const float wgt = ww * (1.0f - nx) * (1.0f - ny) * mod;
-                            float*      cell = &s_hist[((iy << 2) + ix) << 3];
-                            atomicAdd(&cell[b0], (1.0f - do0) * wgt);
-                            atomicAdd(&cell[b1], do0 * wgt);
+                            const float wgt = wm * (1.0f - nx) * (1.0f - ny);
+                            fix64*      cell = &hist[((iy << 2) + ix) << 3];
+                            atomicAdd(&cell[b0], to_fix((1.0f - do0) * wgt));
+                            atomicAdd(&cell[b1], to_fix(do0 * wgt));
                         }
                     }
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
 
-        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134) */
-        float val = (tid < 128) ? s_hist[tid] : 0.0f;
+        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
+        float v0 = from_fix(hist[lane]), v1 = from_fix(hist[lane + 64]);
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
-            float sum = val;
+            float sum = v0 + v1;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
-            if (lane == 0) s_red[wave] = sum;
-            __syncthreads();
-            sum = s_red[0] + s_red[1];
-            val = scalbnf(sqrtf(val / sum), sc.norm_multi);
+            v0 = scalbnf(sqrtf(v0 / sum), sc.norm_multi);
+            v1 = scalbnf(sqrtf(v1 / sum), sc.norm_multi);
         } else {
-            float sq = val * val;
+            float sq = v0 * v0 + v1 * v1;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
-            if (lane == 0) s_red[wave] = sq;
-            __syncthreads();
-            const float norm = sqrtf(s_red[0] + s_red[1]);
-            __syncthreads();
-            val = fminf(val, 0.2f * norm);
-            sq = val * val;
+            const float norm = sqrtf(sq);
+            v0 = fminf(v0, 0.2f * norm);
+            v1 = fminf(v1, 0.2f * norm);
+            sq = v0 * v0 + v1 * v1;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
-            if (lane == 0) s_red[wave] = sq;
-            __syncthreads();
-            float rn = 1.0f / sqrtf(s_red[0] + s_red[1]);
+            float rn = 1.0f / sqrtf(sq);
             rn = scalbnf(rn, sc.norm_multi);
-            val = val * rn;
+            v0 = v0 * rn;
+            v1 = v1 * rn;
         }
-        if (tid < 128) desc[(size_t)d * 128 + tid] = val;
-        __syncthreads();
+        desc[(size_t)d * 128 + lane] = v0;
+        desc[(size_t)d * 128 + 64 + lane] = v1;
+        wave_lds_sync();
     }
 }
 
@@ -414,21 +452,21 @@ __global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __r
 
 }  // namespace
 
-hipError_t launch_orientation(const PyrDesc& pd, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
+hipError_t launch_orientation(const PyrDesc* pd, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
                               Ext* ext, int blocks, hipStream_t s)
 {
     hipLaunchKernelGGL(k_orientation, dim3(blocks), dim3(256), 0, s, pd, sc, ct, iext, ext);
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const PyrDesc& pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* map, int desc_cap,
+hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* map, int desc_cap,
                        hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, pd, sc, ct, ext, map, desc_cap);
     return hipGetLastError();
 }
 
-hipError_t launch_descriptors(const PyrDesc& pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
+hipError_t launch_descriptors(const PyrDesc* pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
                               const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
 {
     hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, sc, ct, ext, map, desc, desc_cap);

@@ -96,38 +96,88 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 
     /* ---- phase 1: stage source tile (+halo) with clamp addressing -------- */
     if (MODE == 0) {
+        /* 16-byte chunks; all of a lane's loads are issued before the first LDS
+         * store so that one memory latency covers the whole tile.  Chunks that
+         * touch the left/right image border fall back to clamped scalar loads. */
+        constexpr int CH = SW / 4;                 /* chunks per row   */
+        constexpr int NCH = SR * CH;               /* chunks per tile  */
+        constexpr int NLD = (NCH + NT - 1) / NT;   /* chunks per lane  */
         const float* __restrict__ src = a.src;
-        for (int idx = tid; idx < SR * SW; idx += NT) {
-            const int r = idx / SW, c = idx - r * SW;
-            const int gx = clampi(tx0 + c - HP, 0, w - 1);
-            const int gy = clampi(ty0 + r - HALO, 0, h - 1);
-            s_src[idx] = src[(size_t)gy * pitch + gx];
+        float4 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int idx = tid + k * NT;
+            if (idx < NCH) {
+                const int    r = idx / CH, c4 = idx - r * CH;
+                const int    gy = clampi(ty0 + r - HALO, 0, h - 1);
+                const int    gx0 = tx0 + 4 * c4 - HP;
+                const float* row = src + (size_t)gy * pitch;
+                if (gx0 >= 0 && gx0 + 3 < w) {
+                    v[k] = *reinterpret_cast<const float4*>(row + gx0);
+                } else {
+                    v[k].x = row[clampi(gx0 + 0, 0, w - 1)];
+                    v[k].y = row[clampi(gx0 + 1, 0, w - 1)];
+                    v[k].z = row[clampi(gx0 + 2, 0, w - 1)];
+                    v[k].w = row[clampi(gx0 + 3, 0, w - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int idx = tid + k * NT;
+            if (idx < NCH) reinterpret_cast<float4*>(s_src)[idx] = v[k];
         }
     } else {
-        /* s_pyramid_build_ra.cu:38-39: read_x = (x + shift) / dst_w (normalised) */
+        /* s_pyramid_build_ra.cu:38-39: read_x = (x + shift) / dst_w (normalised).
+         * Per-column / per-row sample coordinates are computed once per tile. */
+        __shared__ int   s_ix[SW];
+        __shared__ float s_fa[SW];
+        __shared__ int   s_iy[SR];
+        __shared__ float s_fb[SR];
+        __shared__ float s_lut[256]; /* cudaReadModeNormalizedFloat: v / 255 */
+        if (MODE == 1) s_lut[tid] = (float)tid / 255.0f;
+        for (int c = tid; c < SW; c += NT) {
+            const int   X = tx0 + c - HP;
+            const float read_x = ((float)X + a.shift) / (float)w;
+            int         ix;
+            float       fa;
+            lin_coord(read_x, a.in_w, ix, fa);
+            s_ix[c] = ix;
+            s_fa[c] = fa;
+        }
+        for (int r = tid; r < SR; r += NT) {
+            const int   Y = clampi(ty0 + r - HALO, 0, h - 1);
+            const float read_y = ((float)Y + a.shift) / (float)h;
+            int         iy;
+            float       fb;
+            lin_coord(read_y, a.in_h, iy, fb);
+            s_iy[r] = iy;
+            s_fb[r] = fb;
+        }
+        __syncthreads();
+#pragma unroll 4
         for (int idx = tid; idx < SR * SW; idx += NT) {
             const int   r = idx / SW, c = idx - r * SW;
-            const int   X = tx0 + c - HP;
-            const int   Y = clampi(ty0 + r - HALO, 0, h - 1);
-            const float read_x = ((float)X + a.shift) / (float)w;
-            const float read_y = ((float)Y + a.shift) / (float)h;
-            int         ix, iy;
-            float       fa, fb;
-            lin_coord(read_x, a.in_w, ix, fa);
-            lin_coord(read_y, a.in_h, iy, fb);
-            float t00, t10, t01, t11;
+            const int   ix = s_ix[c], iy = s_iy[r];
+            const float fa = s_fa[c], fb = s_fb[r];
+            const int   x0 = clampi(ix, 0, a.in_w - 1), x1 = clampi(ix + 1, 0, a.in_w - 1);
+            const int   y0 = clampi(iy, 0, a.in_h - 1), y1 = clampi(iy + 1, 0, a.in_h - 1);
+            float       t00, t10, t01, t11;
             if (MODE == 1) {
-                const uint8_t* img = (const uint8_t*)a.in;
-                t00 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix, iy);
-                t10 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy);
-                t01 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix, iy + 1);
-                t11 = texel<uint8_t>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy + 1);
+                const uint8_t* r0 = (const uint8_t*)a.in + (size_t)y0 * a.in_pitch;
+                const uint8_t* r1 = (const uint8_t*)a.in + (size_t)y1 * a.in_pitch;
+                const int      b00 = r0[x0], b10 = r0[x1], b01 = r1[x0], b11 = r1[x1];
+                t00 = s_lut[b00];
+                t10 = s_lut[b10];
+                t01 = s_lut[b01];
+                t11 = s_lut[b11];
             } else {
-                const float* img = (const float*)a.in;
-                t00 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix, iy);
-                t10 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy);
-                t01 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix, iy + 1);
-                t11 = texel<float>(img, a.in_w, a.in_h, a.in_pitch, ix + 1, iy + 1);
+                const float* r0 = (const float*)a.in + (size_t)y0 * a.in_pitch;
+                const float* r1 = (const float*)a.in + (size_t)y1 * a.in_pitch;
+                t00 = r0[x0];
+                t10 = r0[x1];
+                t01 = r1[x0];
+                t11 = r1[x1];
             }
             const float top = (1.0f - fa) * t00 + fa * t10;
             const float bot = (1.0f - fa) * t01 + fa * t11;

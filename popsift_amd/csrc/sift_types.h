@@ -21,7 +21,7 @@ struct OctDesc {
     float*  dog;          /* L-1 DoG planes      */
     int64_t plane_stride; /* floats per plane = pitch * h */
     int     w, h, pitch;
-    int     tile_begin;   /* first block of this octave in whole-pyramid launches */
+    int     tile_begin;   /* first wave-sized work unit of this octave in the detection launch */
 };
 
 struct PyrDesc {

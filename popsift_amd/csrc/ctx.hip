@@ -279,7 +279,7 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     return 0;
 }
 
-int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, double alg_bytes)
+int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int tile_h, double alg_bytes)
 {
     if (c->profile) {
         if (c->blur_events_used == c->blur_events.size()) {
@@ -291,10 +291,10 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, doubl
         EventPair& ep = c->blur_events[c->blur_events_used++];
         ep.bytes = alg_bytes;
         HIP_TRY(c, hipEventRecord(ep.a, c->stream));
-        HIP_TRY(c, launch_blur(a, mode, span, c->stream));
+        HIP_TRY(c, launch_blur(a, mode, span, tile_h, c->stream));
         HIP_TRY(c, hipEventRecord(ep.b, c->stream));
     } else {
-        HIP_TRY(c, launch_blur(a, mode, span, c->stream));
+        HIP_TRY(c, launch_blur(a, mode, span, tile_h, c->stream));
     }
     return 0;
 }
@@ -303,13 +303,14 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, doubl
 int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch)
 {
     const PyrDesc& pd = c->pd;
-    const int      twd = blur_tile_w(), thd = blur_tile_h();
+    const int      twd = blur_tile_w();
     for (int o = 0; o < pd.n_oct; o++) {
         const OctDesc& od = pd.o[o];
         BlurArgs       a{};
         a.w = od.w;
         a.h = od.h;
         a.pitch = od.pitch;
+        const int thd = blur_tile_h(od.w, od.h);
         a.tiles_x = (od.w + twd - 1) / twd;
         a.tiles_y = (od.h + thd - 1) / thd;
         const double px = (double)od.w * od.h;
@@ -330,7 +331,7 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
                     a.in_pitch = pitch;
                     a.shift = shift;
                     const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * px;
-                    if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], bytes)) return rc;
+                    if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
                 } else {
                     const OctDesc& pv = pd.o[o - 1];
                     HIP_TRY(c, launch_decimate(pv.data + (pd.L - 3) * pv.plane_stride, pv.w, pv.h, pv.pitch, a.dst,
@@ -341,7 +342,7 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
                 a.dog = od.dog + (level - 1) * od.plane_stride;
                 a.in = nullptr;
                 /* read plane l-1 once, write plane l and DoG l-1 once: 12 B / pixel */
-                if (int rc = blur_launch(c, a, 0, c->tab.span[level], 12.0 * px)) return rc;
+                if (int rc = blur_launch(c, a, 0, c->tab.span[level], thd, 12.0 * px)) return rc;
             }
         }
     }
@@ -353,9 +354,9 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
     HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_iext, c->stream));
-    HIP_TRY(c, launch_orientation(c->d_pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 2048, c->stream));
+    HIP_TRY(c, launch_orientation(c->d_pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 8192, c->stream));
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->desc_cap, c->stream));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 2048,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 16384,
                                   c->stream));
     HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));

@@ -23,8 +23,8 @@ struct BlurArgs {
 };
 
 int        blur_tile_w();
-int        blur_tile_h();
-hipError_t launch_blur(const BlurArgs& a, int mode, int span, hipStream_t s);
+int        blur_tile_h(int w, int h); /* 32 or 64 rows, by plane size */
+hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s);
 hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* dst, int dw, int dh,
                            int dpitch, hipStream_t s);
 

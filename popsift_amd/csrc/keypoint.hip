@@ -35,8 +35,30 @@ constexpr float            DESC_MAGNIFY = 3.0f;
  * histograms, unlike the reference's float atomicAdd, s_orientation.cu:136).
  */
 typedef unsigned long long fix64;
-__device__ __forceinline__ fix64 to_fix(float w) { return (fix64)(w * 4294967296.0f); }
-__device__ __forceinline__ float from_fix(fix64 v) { return (float)((double)v * (1.0 / 4294967296.0)); }
+/* one sample weighs < 2^11 (|gradient| <= 255*2*sqrt2, window weights <= 1): w * 2^20 fits 32 bits */
+__device__ __forceinline__ fix64 to_fix(float w) { return (fix64)(unsigned int)(w * 1048576.0f); }
+__device__ __forceinline__ float from_fix(fix64 v) { return (float)((double)v * (1.0 / 1048576.0)); }
+
+/* atan2 for the descriptor's *soft* orientation binning (continuous in theta, so ~3e-7 rad
+ * of error is immaterial; the reference itself uses fast intrinsics there, s_desc_loop.cu:48,97).
+ * Cephes-style: reduce to |t| <= tan(pi/8), odd degree-9 polynomial, v_rcp instead of IEEE division. */
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float       a = mn * __builtin_amdgcn_rcpf(mx);
+    a = (mx == 0.0f) ? 0.0f : a;
+    const bool  big = a > 0.41421356f;
+    const float t = big ? (a - 1.0f) * __builtin_amdgcn_rcpf(a + 1.0f) : a;
+    const float s = t * t;
+    const float p = fmaf(fmaf(fmaf(8.05374449538e-2f, s, -1.38776856032e-1f), s, 1.99777106478e-1f), s,
+                         -3.33329491539e-1f);
+    float       r = fmaf(t * s, p, t);
+    r = big ? r + 0.785398163f : r;
+    r = (ay > ax) ? 1.570796327f - r : r;
+    r = (x < 0.0f) ? 3.141592654f - r : r;
+    return (y < 0.0f) ? -r : r;
+}
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -302,14 +324,19 @@ __global__ __launch_bounds__(1024) void k_scan(const PyrDesc* __restrict__ pdp, 
  * a different summation order.  The 128-bin histogram lives in LDS (per wave),
  * is normalised in registers and leaves as two coalesced 256 B rows.
  */
-__global__ __launch_bounds__(256) void k_descriptor(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+__global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict__ pdp, SiftConsts sc,
                                                     const Counters* __restrict__ ct, const Ext* __restrict__ ext,
                                                     const int* __restrict__ map, float* __restrict__ desc,
                                                     int desc_cap)
 {
-    __shared__ fix64 s_hist[4][128];
+    /* DCOPY private copies of the histogram per wave: neighbouring lanes sample neighbouring
+     * pixels, which mostly fall into the same cell and orientation bin; spreading them over
+     * copies by lane cuts the same-address serialisation of the LDS atomics */
+    constexpr int    DCOPY = 4;
+    __shared__ fix64 s_hist[4][DCOPY][128];
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    fix64*           hist = s_hist[wave];
+    fix64*           hist = s_hist[wave][lane & (DCOPY - 1)];
+    fix64*           hall = s_hist[wave][0];
     const int        total = min(ct->ori_total, desc_cap);
     const int        L = pdp->L;
     const float      M_4RPI = 4.0f / F_PI;
@@ -324,8 +351,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const PyrDesc* __restrict__ 
         const int      lvl = min(max(e->lpos, 0), L - 1);
         const float*   layer = od->data + lvl * od->plane_stride;
 
-        hist[lane] = 0ull;
-        hist[lane + 64] = 0ull;
+#pragma unroll
+        for (int k = 0; k < 2 * DCOPY; k++) hall[lane + 64 * k] = 0ull;
         wave_lds_sync();
 
         const float SBP = fabsf(DESC_MAGNIFY * sigma);
@@ -360,43 +387,60 @@ __global__ __launch_bounds__(256) void k_descriptor(const PyrDesc* __restrict__ 
                     const float  gx = c[1] - c[-1];
                     const float  gy = c[pitch] - c[-pitch];
                     const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
-                    float        th = atan2f(gy, gx);
+                    float        th = fast_atan2(gy, gx);
                     const float  ww = __expf(-0.125f * (u * u + v * v));
 
                     th -= ang;
                     th += (th < 0.0f ? F_PI2 : 0.0f);
                     th -= (th >= F_PI2 ? F_PI2 : 0.0f);
                     const float tth = th * M_4RPI;
-                    const int   fo0 = (int)floorf(tth);
-                    const float do0 = tth - fo0;
+                    const float ffo = floorf(tth);
+                    const float do0 = tth - ffo;
+                    const int   fo0 = (int)ffo;
                     const int   b0 = fo0 & 7, b1 = (fo0 + 1) & 7;
 
-                    const float tu = u + 1.5f, tv = v + 1.5f; /* cell centres at 0..3 */
-                    const int   cx0 = (int)floorf(tu), cy0 = (int)floorf(tv);
+                    /* cell centres sit at integer tu, tv in 0..3; the sample feeds cells
+                     * (cx0, cx0+1) x (cy0, cy0+1) with weights (1-fx, fx) x (1-fy, fy)
+                     * -- the (1-|n.x|)(1-|n.y|) of s_desc_loop.cu:100-102 -- where inside 0..3 */
+                    const float tu = u + 1.5f, tv = v + 1.5f;
+                    const float fcx = floorf(tu), fcy = floorf(tv);
+                    const float fx = tu - fcx, fy = tv - fcy;
+                    const int   cx0 = (int)fcx, cy0 = (int)fcy;
                     const float wm = ww * mod;
-#pragma unroll
-                    for (int cy = 0; cy < 2; cy++) {
-                        const int   iy = cy0 + cy;
-                        const float ny = fabsf(tv - iy);
-                        if (iy < 0 || iy > 3 || !(ny < 1.0f)) continue;
-#pragma unroll
-                        for (int cxi = 0; cxi < 2; cxi++) {
-                            const int   ix = cx0 + cxi;
-                            const float nx = fabsf(tu - ix);
-                            if (ix < 0 || ix > 3 || !(nx < 1.0f)) continue;
-                            const float wgt = wm * (1.0f - nx) * (1.0f - ny);
-                            fix64*      cell = &hist[((iy << 2) + ix) << 3];
-                            atomicAdd(&cell[b0], to_fix((1.0f - do0) * wgt));
-                            atomicAdd(&cell[b1], to_fix(do0 * wgt));
-                        }
-                    }
+                    const float wx0 = (cx0 >= 0) ? 1.0f - fx : 0.0f;
+                    const float wx1 = (cx0 <= 2) ? fx : 0.0f;
+                    const float wy0 = (cy0 >= 0) ? (1.0f - fy) * wm : 0.0f;
+                    const float wy1 = (cy0 <= 2) ? fy * wm : 0.0f;
+                    const int   ix0 = max(cx0, 0), ix1 = min(cx0 + 1, 3);
+                    const int   iy0 = max(cy0, 0), iy1 = min(cy0 + 1, 3);
+                    const float w1 = do0, w0 = 1.0f - do0;
+#define PS_CELL(IY, IX, WGT)                                                \
+    {                                                                       \
+        const float wgt = (WGT);                                            \
+        if (wgt > 0.0f) {                                                   \
+            fix64* cell = &hist[(((IY) << 2) + (IX)) << 3];                 \
+            atomicAdd(&cell[b0], to_fix(w0 * wgt));                         \
+            atomicAdd(&cell[b1], to_fix(w1 * wgt));                         \
+        }                                                                   \
+    }
+                    PS_CELL(iy0, ix0, wy0 * wx0)
+                    PS_CELL(iy0, ix1, wy0 * wx1)
+                    PS_CELL(iy1, ix0, wy1 * wx0)
+                    PS_CELL(iy1, ix1, wy1 * wx1)
+#undef PS_CELL
                 }
             }
         }
         wave_lds_sync();
 
         /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
-        float v0 = from_fix(hist[lane]), v1 = from_fix(hist[lane + 64]);
+        fix64 a0 = 0ull, a1 = 0ull;
+#pragma unroll
+        for (int k = 0; k < DCOPY; k++) {
+            a0 += hall[k * 128 + lane];
+            a1 += hall[k * 128 + lane + 64];
+        }
+        float v0 = from_fix(a0), v1 = from_fix(a1);
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
 #pragma unroll

@@ -8,8 +8,8 @@
  *   gauss::make_dog                 (s_pyramid_build.cu:74-92)
  *   gauss::get_by_2_pick_every_second (s_pyramid_build.cu:50-71)
  * by ONE kernel per level: stage the source tile (+halo) in LDS, horizontal
- * pass LDS->LDS with a register window (4 outputs / lane, ds_read_b128),
- * vertical pass from LDS with a register window (16 outputs / lane), write the
+ * pass in place in LDS with a register window (4 outputs / lane, ds_read_b128),
+ * vertical pass from LDS with a register window (4x4 outputs / lane), write the
  * Gaussian plane and the DoG plane.  No intermediate plane ever reaches HBM.
  *
  * Arithmetic is kept in the reference's order (outermost tap first, explicit
@@ -20,6 +20,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sift_types.h"
 #include "kernels.h"
 
@@ -28,7 +30,6 @@ namespace popsift_hip {
 namespace {
 
 constexpr int TW = 128; /* tile width  (outputs) */
-constexpr int TH = 32;  /* tile height (outputs) */
 constexpr int NT = 256; /* threads per workgroup */
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -70,23 +71,31 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 /*
  * MODE 0: level l >= 1 from plane l-1 (centre tap first in the H pass, DoG out)
  * MODE 1: octave 0 level 0 from the u8 input image (bilinear upscale on the fly)
  * MODE 2: octave 0 level 0 from the f32 input image
+ *
+ * One LDS buffer of (TH + 2*HALO) rows x (TW + 2*HP) floats:
+ *   phase 1  stage the source tile + halo (16 B chunks, every load in flight at once)
+ *   phase 2  horizontal pass IN PLACE: a row is owned by 32 lanes of one wave,
+ *            which read their 9 x ds_read_b128 windows before the ds_write_b128
+ *   phase 3  vertical pass, 4 columns x 4 rows per lane from a register window
+ *            of ds_read_b128 rows; 16 B stores of the Gaussian plane and of
+ *            DoG = new - old (old re-read from L2 as one 16 B load)
  */
-template <int HALO, int MODE>
+template <int HALO, int MODE, int TH>
 __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 {
     constexpr int HP = (HALO + 3) & ~3;   /* left/right halo, padded to 16 B   */
-    constexpr int SW = TW + 2 * HP;       /* LDS row pitch of the source tile  */
+    constexpr int SW = TW + 2 * HP;       /* LDS row pitch                     */
     constexpr int SR = TH + 2 * HALO;     /* rows staged                       */
-    constexpr int WIN = 4 + 2 * HP;       /* H-pass register window (floats)   */
-    constexpr int VO = TH / 2;            /* V-pass outputs per lane           */
-    constexpr int VWIN = VO + 2 * HALO;
+    constexpr int NW = 1 + HP / 2;        /* H-pass window in 16 B chunks      */
+    constexpr int VW = 4 + 2 * HALO;      /* V-pass window rows                */
 
-    __shared__ __attribute__((aligned(16))) float s_src[SR * SW];
-    __shared__ __attribute__((aligned(16))) float s_hb[SR * TW];
+    __shared__ __attribute__((aligned(16))) float s_t[SR * SW];
 
     const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
     const int tx0 = (tile % a.tiles_x) * TW;
@@ -96,14 +105,11 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 
     /* ---- phase 1: stage source tile (+halo) with clamp addressing -------- */
     if (MODE == 0) {
-        /* 16-byte chunks; all of a lane's loads are issued before the first LDS
-         * store so that one memory latency covers the whole tile.  Chunks that
-         * touch the left/right image border fall back to clamped scalar loads. */
         constexpr int CH = SW / 4;                 /* chunks per row   */
         constexpr int NCH = SR * CH;               /* chunks per tile  */
         constexpr int NLD = (NCH + NT - 1) / NT;   /* chunks per lane  */
         const float* __restrict__ src = a.src;
-        float4 v[NLD];
+        v4f v[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
             const int idx = tid + k * NT;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                 const int    gx0 = tx0 + 4 * c4 - HP;
                 const float* row = src + (size_t)gy * pitch;
                 if (gx0 >= 0 && gx0 + 3 < w) {
-                    v[k] = *reinterpret_cast<const float4*>(row + gx0);
+                    v[k] = *reinterpret_cast<const v4f*>(row + gx0);
                 } else {
                     v[k].x = row[clampi(gx0 + 0, 0, w - 1)];
                     v[k].y = row[clampi(gx0 + 1, 0, w - 1)];
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
             const int idx = tid + k * NT;
-            if (idx < NCH) reinterpret_cast<float4*>(s_src)[idx] = v[k];
+            if (idx < NCH) reinterpret_cast<v4f*>(s_t)[idx] = v[k];
         }
     } else {
         /* s_pyramid_build_ra.cu:38-39: read_x = (x + shift) / dst_w (normalised).
@@ -181,73 +187,78 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
             }
             const float top = (1.0f - fa) * t00 + fa * t10;
             const float bot = (1.0f - fa) * t01 + fa * t11;
-            s_src[idx] = (1.0f - fb) * top + fb * bot;
+            s_t[idx] = (1.0f - fb) * top + fb * bot;
         }
     }
     __syncthreads();
 
-    /* ---- phase 2: horizontal pass, 4 outputs per lane -------------------- */
+    /* ---- phase 2: horizontal pass in place, 4 outputs per lane ----------- */
     {
         const int lx = (tid & 31) * 4; /* first output column of this lane */
         for (int r = tid >> 5; r < SR; r += NT / 32) {
-            float         win[WIN];
-            const float4* p = reinterpret_cast<const float4*>(&s_src[r * SW + lx]);
+            v4f        win[NW];
+            const v4f* p = reinterpret_cast<const v4f*>(&s_t[r * SW + lx]);
 #pragma unroll
-            for (int j = 0; j < WIN / 4; j++) {
-                const float4 v = p[j];
-                win[4 * j + 0] = v.x;
-                win[4 * j + 1] = v.y;
-                win[4 * j + 2] = v.z;
-                win[4 * j + 3] = v.w;
-            }
-            float out[4];
+            for (int j = 0; j < NW; j++) win[j] = p[j];
+#define PS_W(i) win[(i) >> 2][(i) & 3]
+            v4f out;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
-                const int cpos = HP + o; /* centre of output o inside win[] */
+                const int cpos = HP + o; /* centre of output o inside the window */
                 float     acc;
                 if (MODE == 0) {
-                    acc = win[cpos] * a.taps.g[0];
+                    acc = PS_W(cpos) * a.taps.g[0];
 #pragma unroll
                     for (int k = HALO; k > 0; k--)
-                        acc = fmaf(win[cpos - k] + win[cpos + k], a.taps.g[k], acc);
+                        acc = fmaf(PS_W(cpos - k) + PS_W(cpos + k), a.taps.g[k], acc);
                 } else {
                     acc = 0.0f;
 #pragma unroll
                     for (int k = HALO; k > 0; k--)
-                        acc = fmaf(win[cpos - k] + win[cpos + k], a.taps.g[k], acc);
-                    acc = fmaf(win[cpos], a.taps.g[0], acc);
+                        acc = fmaf(PS_W(cpos - k) + PS_W(cpos + k), a.taps.g[k], acc);
+                    acc = fmaf(PS_W(cpos), a.taps.g[0], acc);
                     acc = acc * 255.0f;
                 }
                 out[o] = acc;
             }
-            *reinterpret_cast<float4*>(&s_hb[r * TW + lx]) = make_float4(out[0], out[1], out[2], out[3]);
+#undef PS_W
+            /* every lane of this row has issued its reads above (same wave, in order) */
+            *reinterpret_cast<v4f*>(&s_t[r * SW + HP + lx]) = out;
         }
     }
     __syncthreads();
 
-    /* ---- phase 3: vertical pass, VO outputs per lane, + DoG -------------- */
+    /* ---- phase 3: vertical pass, 4 columns x 4 rows per lane, + DoG ------ */
     {
-        const int cx = tid & (TW - 1);
-        const int r0 = (tid / TW) * VO; /* first output row (tile-relative) */
-        float     win[VWIN];
-#pragma unroll
-        for (int j = 0; j < VWIN; j++) win[j] = s_hb[(r0 + j) * TW + cx];
+        const int cx = (tid & 31) * 4;
         const int gx = tx0 + cx;
+        for (int rg = tid >> 5; rg < TH / 4; rg += NT / 32) {
+            const int r0 = rg * 4; /* first output row (tile-relative) */
+            v4f       win[VW];
 #pragma unroll
-        for (int o = 0; o < VO; o++) {
-            const int cpos = HALO + o;
-            float     acc = 0.0f;
+            for (int j = 0; j < VW; j++) win[j] = *reinterpret_cast<const v4f*>(&s_t[(r0 + j) * SW + HP + cx]);
 #pragma unroll
-            for (int k = HALO; k > 0; k--) {
-                acc = fmaf(win[cpos - k], a.taps.g[k], acc);
-                acc = fmaf(win[cpos + k], a.taps.g[k], acc);
-            }
-            acc = fmaf(win[cpos], a.taps.g[0], acc);
-            const int gy = ty0 + r0 + o;
-            if (gx < w && gy < h) {
-                a.dst[(size_t)gy * pitch + gx] = acc;
-                if (MODE == 0)
-                    a.dog[(size_t)gy * pitch + gx] = acc - s_src[(r0 + o + HALO) * SW + cx + HP];
+            for (int o = 0; o < 4; o++) {
+                const int cpos = HALO + o;
+                v4f       acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = HALO; k > 0; k--) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = fmaf(win[cpos - k][e], a.taps.g[k], acc[e]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = fmaf(win[cpos + k][e], a.taps.g[k], acc[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[e] = fmaf(win[cpos][e], a.taps.g[0], acc[e]);
+                const int gy = ty0 + r0 + o;
+                if (gx < w && gy < h) {
+                    /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */
+                    *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
+                    if (MODE == 0) {
+                        const v4f old = *reinterpret_cast<const v4f*>(&a.src[(size_t)gy * pitch + gx]);
+                        *reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]) = acc - old;
+                    }
+                }
             }
         }
     }
@@ -265,14 +276,14 @@ __global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src,
     dst[(size_t)y * dpitch + x] = src[(size_t)ry * spitch + rx];
 }
 
-template <int MODE>
+template <int MODE, int TH>
 hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
 {
     const dim3 grid(a.tiles_x * a.tiles_y), block(NT);
-#define PS_CASE(H)                                               \
-    if (halo <= H) {                                             \
-        hipLaunchKernelGGL((k_blur_tile<H, MODE>), grid, block, 0, s, a); \
-        return hipGetLastError();                                \
+#define PS_CASE(H)                                                             \
+    if (halo <= H) {                                                           \
+        hipLaunchKernelGGL((k_blur_tile<H, MODE, TH>), grid, block, 0, s, a);  \
+        return hipGetLastError();                                              \
     }
     PS_CASE(4)
     PS_CASE(5)
@@ -291,16 +302,36 @@ hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
 }  // namespace
 
 int blur_tile_w() { return TW; }
-int blur_tile_h() { return TH; }
 
-hipError_t launch_blur(const BlurArgs& a, int mode, int span, hipStream_t s)
+/* 64-row tiles cut the halo re-computation of the horizontal pass (1.4x instead of
+ * 1.8x at 27 taps) but need 4x the pixels per workgroup: use them where the plane
+ * still yields a few tiles per CU */
+int blur_tile_h(int w, int h)
+{
+    static const long min_tiles = []() {
+        const char* e = getenv("POPSIFT_HIP_TILE64_MIN"); /* tuning knob */
+        return e ? atol(e) : 1024L;
+    }();
+    const long tiles64 = (long)((w + TW - 1) / TW) * ((h + 63) / 64);
+    return tiles64 >= min_tiles ? 64 : 32;
+}
+
+hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s)
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    switch (mode) {
-    case 0: return launch_blur_mode<0>(a, halo, s);
-    case 1: return launch_blur_mode<1>(a, halo, s);
-    case 2: return launch_blur_mode<2>(a, halo, s);
+    if (tile_h == 64) {
+        switch (mode) {
+        case 0: return launch_blur_mode<0, 64>(a, halo, s);
+        case 1: return launch_blur_mode<1, 64>(a, halo, s);
+        case 2: return launch_blur_mode<2, 64>(a, halo, s);
+        }
+    } else if (tile_h == 32) {
+        switch (mode) {
+        case 0: return launch_blur_mode<0, 32>(a, halo, s);
+        case 1: return launch_blur_mode<1, 32>(a, halo, s);
+        case 2: return launch_blur_mode<2, 32>(a, halo, s);
+        }
     }
     return hipErrorInvalidValue;
 }

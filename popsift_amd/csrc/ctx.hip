@@ -62,6 +62,8 @@ struct popsift_hip_ctx {
     /* device memory (grow-only) */
     void*   d_input = nullptr;
     size_t  input_cap = 0;
+    void*   h_input = nullptr; /* pinned staging: submit() copies the caller's image before returning */
+    size_t  h_input_cap = 0;
     float*  d_arena = nullptr;
     size_t  arena_cap = 0; /* floats */
     PyrDesc pd{};
@@ -382,8 +384,20 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
         if (int rc = grow(c, &buf, &cap, (size_t)w * h * esz)) return rc;
         c->d_input = buf;
         c->input_cap = cap;
-        HIP_TRY(c, hipMemcpy2DAsync(c->d_input, (size_t)w * esz, img, (size_t)pitch * esz, (size_t)w * esz, h,
-                                    hipMemcpyHostToDevice, c->stream));
+        /* Like Image::load (s_image.cu:71-79) the caller's buffer is copied into pinned memory before
+         * this call returns: the caller may free or reuse it immediately (popsift.cpp:245-247), and an
+         * async copy straight from pageable memory would read it later. */
+        const size_t bytes = (size_t)w * h * esz;
+        if (bytes > c->h_input_cap) {
+            if (c->h_input) HIP_TRY(c, hipHostFree(c->h_input));
+            c->h_input = nullptr;
+            c->h_input_cap = 0;
+            HIP_TRY(c, hipHostMalloc(&c->h_input, bytes, hipHostMallocDefault));
+            c->h_input_cap = bytes;
+        }
+        for (int y = 0; y < h; y++)
+            memcpy((char*)c->h_input + (size_t)y * w * esz, (const char*)img + (size_t)y * pitch * esz, (size_t)w * esz);
+        HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_input, bytes, hipMemcpyHostToDevice, c->stream));
         d_img = c->d_input;
         dpitch = w;
     }
@@ -566,6 +580,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->d_input) (void)hipFree(c->d_input);
+    if (c->h_input) (void)hipHostFree(c->h_input);
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_iext) (void)hipFree(c->d_iext);
     if (c->d_ext) (void)hipFree(c->d_ext);

@@ -1,0 +1,235 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full
+sizes -- through size-independent properties.
+
+Bars: pyramid / DoG planes and the refined extremum positions are BIT-EXACT (same expression
+order, -ffp-contract=off on both sides).  Orientations and descriptors go through device
+libm (atan2f, expf) and a different summation order: >= 99.8 % of the descriptors must be
+within 1e-3 relative L2 of the oracle's (BASELINE.json: "descriptors within 1e-3 relative");
+the rest are keypoints where an ulp-level atan2f difference moves one sample across a hard
+orientation-histogram bin (s_orientation.cu:129), which is bounded below at 3e-2."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from popsift_amd.synth import gaussian_blob, synth
+from util import bits, compare_features, sorted_features
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("default_200x150", dict(), (7, 200, 150)),
+    ("cfg1_vlfeat_3oct_640x480", dict(octaves=3, sift_mode=2), (1, 640, 480)),
+    ("opencv_odd_333x257", dict(sift_mode=1, gauss_mode=3), (5, 333, 257)),
+    ("classic_norm_multi9", dict(norm_mode=1, norm_multi=9), (14, 160, 120)),
+    ("levels2_sigma1p2", dict(levels=2, sigma=1.2), (15, 150, 100)),
+    ("levels5", dict(levels=5), (16, 140, 110)),
+    ("no_upscale", dict(upscale_factor=0.0), (17, 320, 240)),
+    ("downsample", dict(upscale_factor=-1.0), (18, 400, 300)),
+    ("no_initial_blur", dict(assume_initial_blur=0, initial_blur=0.0), (19, 130, 90)),
+    ("tiny_17x13", dict(), (20, 17, 13)),
+    ("thin_300x9", dict(), (25, 300, 9)),
+    ("edge_limit_threshold", dict(edge_limit=5.0, threshold=0.08), (26, 256, 192)),
+]
+
+
+def run_both(O, hip, kw, img, threads=8):
+    orc = O.Oracle(O.default_params(**kw), threads=threads).run(img)
+    ctx = hip.Context(hip.default_params(**kw))
+    ctx.submit(img)
+    return orc, ctx
+
+
+def assert_planes_equal(orc, ctx, levels):
+    assert ctx.report().num_octaves == orc.num_octaves
+    for o in range(orc.num_octaves):
+        assert ctx.octave_dims(o) == orc.octave_dims(o)
+        for kind, n in ((0, levels + 3), (1, levels + 2)):
+            for l in range(n):
+                a, b = orc.plane(o, kind, l), ctx.plane(o, kind, l)
+                assert np.array_equal(bits(a), bits(b)), "octave %d kind %d level %d: %d values differ, max %g" % (
+                    o, kind, l, int((bits(a) != bits(b)).sum()), float(np.abs(a - b).max()))
+
+
+def assert_keypoints_match(orc, ctx):
+    eo, eh = orc.extrema(), ctx.extrema()
+    key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
+    assert key(eo) == key(eh)                       # same set, bit-exact positions
+    assert orc.ext_counts() == list(ctx.report().ext_ct)[:orc.num_octaves]
+    fo, do = orc.fetch()
+    fh, dh = ctx.fetch()
+    st = compare_features(fo, do, fh, dh)
+    assert st["n_a"] == st["n_b"] == st["matched"] and st["missing"] == 0
+    assert st["max_sigma_rel"] < 1e-5
+    n = max(st["n_desc"], 1)
+    assert st["num_ori_diff"] <= max(1, st["n_a"] // 2000)
+    assert st["desc_bad"] <= max(1, n // 500), st
+    assert st["ang_bad"] <= max(1, n // 500), st
+    assert st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2, st
+    # layout contract of the reference: descriptors feature by feature, octaves ascending
+    idx = np.concatenate([f["desc_idx"][: int(f["num_ori"])] for f in fh]) if len(fh) else np.zeros(0, int)
+    assert np.array_equal(idx, np.arange(len(dh)))
+    assert np.all(np.diff(fh["debug_octave"]) >= 0)
+    return st
+
+
+@pytest.mark.parametrize("name,kw,spec", CASES, ids=[c[0] for c in CASES])
+def test_hip_matches_oracle(oracle_mod, gpu_hip, name, kw, spec):
+    img = synth(*spec)
+    orc, ctx = run_both(oracle_mod, gpu_hip, kw, img)
+    assert_planes_equal(orc, ctx, max(2, kw.get("levels", 3)))
+    assert_keypoints_match(orc, ctx)
+    ctx.close()
+
+
+def test_float_images(oracle_mod, gpu_hip):
+    img = (synth(27, 180, 140).astype(np.float32) / 256.0)   # the demo's byte->float mapping, main.cpp:233
+    orc, ctx = run_both(oracle_mod, gpu_hip, {}, img)
+    assert_planes_equal(orc, ctx, 3)
+    assert_keypoints_match(orc, ctx)
+
+
+def test_analytic_blob(gpu_hip):
+    img = gaussian_blob(140, 128, 61.5, 48.25, 5.0)
+    feats, desc = gpu_hip.Context().submit(img).fetch()
+    d = np.hypot(feats["xpos"] - 61.5, feats["ypos"] - 48.25)
+    i = int(np.argmin(d))
+    assert d[i] < 0.15 and 0.78 * 5.0 < feats["sigma"][i] < 1.05 * 5.0
+
+
+def test_flat_image_gives_valid_empty_result(gpu_hip):
+    ctx = gpu_hip.Context()
+    feats, desc = ctx.submit(np.full((64, 80), 128, np.uint8)).fetch()
+    assert len(feats) == 0 and desc.shape == (0, 128)   # sift_pyramid.cu:290-294
+    assert ctx.report().ext_total == 0
+
+
+def test_gauss_tables_match(oracle_mod, gpu_hip):
+    for kw in (dict(), dict(gauss_mode=3), dict(levels=4, sigma=1.3)):
+        fo, so, go = oracle_mod.Oracle(oracle_mod.default_params(**kw)).gauss_table()
+        fh, sh, gh = gpu_hip.Context(gpu_hip.default_params(**kw)).gauss_table()
+        assert np.array_equal(so, sh) and np.array_equal(bits(fo), bits(fh)) and np.array_equal(bits(go), bits(gh))
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_reproduces_golden(gpu_hip, path):
+    """The fixtures were made on another host: its libm (powf/exp in the Gauss tables, which the
+    reference also computes on the host, gauss_filter.cu:163-372) may differ in the last bit,
+    so this comparison is by tolerance; bit-exactness is asserted against the oracle running
+    on THIS host in test_hip_matches_oracle."""
+    from test_golden import load_case
+    z, kw = load_case(path)
+    ctx = gpu_hip.Context(gpu_hip.default_params(**kw))
+    feats, desc = ctx.submit(z["image"]).fetch()
+    for l in (0, 3):
+        np.testing.assert_allclose(ctx.plane(0, 0, l)[::4, ::4], z["g_o0_l%d" % l], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(ctx.plane(1, 1, 2), z["dog_o1_l2"], rtol=0, atol=2e-3)
+    f, d = sorted_features(feats, desc)
+    n = len(z["xpos"])
+    assert abs(len(f) - n) <= max(2, n // 50)
+    # nearest-neighbour match in (octave, x, y, sigma)
+    hit = dbad = 0
+    off = np.concatenate([[0], np.cumsum(z["num_ori"])])
+    goff = np.concatenate([[0], np.cumsum(f["num_ori"])])
+    for i in range(n):
+        sel = np.nonzero(f["debug_octave"] == z["octave"][i])[0]
+        if len(sel) == 0:
+            continue
+        dist = np.maximum(np.abs(f["xpos"][sel] - z["xpos"][i]), np.abs(f["ypos"][sel] - z["ypos"][i]))
+        j = sel[int(np.argmin(dist))]
+        if dist.min() > 2e-2 * 2.0 ** z["octave"][i] or abs(f["sigma"][j] - z["sigma"][i]) > 1e-2 * z["sigma"][i]:
+            continue
+        hit += 1
+        if f["num_ori"][j] == z["num_ori"][i]:
+            for k in range(int(z["num_ori"][i])):
+                a, b = z["desc"][off[i] + k], d[goff[j] + k]
+                dbad += np.linalg.norm(a - b) > 2e-2 * np.linalg.norm(a)
+    assert hit >= 0.98 * n
+    assert dbad <= max(2, len(z["desc"]) // 50)
+
+
+def test_max_extrema_cap_and_buffer_growth(oracle_mod, gpu_hip):
+    """max_extrema caps every octave (s_extrema.cu:541,558); with a small cap the descriptor buffer
+    (2 * max_extrema, sift_pyramid.cu:149) is outgrown and must be re-grown transparently."""
+    img = synth(13, 320, 240)
+    ctx = gpu_hip.Context(gpu_hip.default_params(max_extrema=300))
+    feats, desc = ctx.submit(img).fetch()
+    rep = ctx.report()
+    assert max(rep.ext_ct) == 300 and rep.ext_total == sum(rep.ext_ct) == len(feats)
+    assert len(desc) == int(feats["num_ori"].sum()) and len(desc) > 0
+    n2 = (desc.astype(np.float64) ** 2).sum(1)
+    np.testing.assert_allclose(n2, 1.0, rtol=1e-4)
+    # the kept extrema are a subset of the uncapped run's
+    full = gpu_hip.Context().submit(img).extrema()
+    capped = ctx.extrema()
+    allk = set(zip(full["octave"].tolist(), full["xpos"].tolist(), full["ypos"].tolist()))
+    assert all(k in allk for k in zip(capped["octave"].tolist(), capped["xpos"].tolist(), capped["ypos"].tolist()))
+
+
+def test_context_reuse_across_sizes_and_determinism(oracle_mod, gpu_hip):
+    """One context, images of different sizes (grow-only buffers; the octave count is frozen by
+    the first image like popsift.cpp:107-111), and bit-reproducible results run to run."""
+    ctx = gpu_hip.Context()
+    a = synth(40, 240, 180)
+    b = synth(41, 96, 64)
+    ra = sorted_features(*ctx.submit(a).fetch())
+    n_oct = ctx.report().num_octaves
+    rb = sorted_features(*ctx.submit(b).fetch())
+    assert ctx.report().num_octaves == n_oct
+    ra2 = sorted_features(*ctx.submit(a).fetch())
+    assert np.array_equal(ra[0]["xpos"], ra2[0]["xpos"]) and np.array_equal(bits(ra[1]), bits(ra2[1]))
+    # the small image with the frozen octave count equals an oracle run with that count forced
+    orc = oracle_mod.Oracle(oracle_mod.default_params(octaves=n_oct), threads=4).run(b)
+    fo, do = sorted_features(*orc.fetch())
+    assert len(fo) == len(rb[0]) and np.array_equal(fo["xpos"], rb[0]["xpos"])
+
+
+def test_two_contexts_are_independent(gpu_hip):
+    imgs = [synth(50 + i, 200, 160) for i in range(4)]
+    solo = [sorted_features(*gpu_hip.Context().submit(im).fetch()) for im in imgs]
+    ctxs = [gpu_hip.Context() for _ in imgs]
+    for c, im in zip(ctxs, imgs):
+        c.submit(im)                      # all four in flight on their own streams
+    for c, s in zip(ctxs, solo):
+        f, d = sorted_features(*c.fetch())
+        assert np.array_equal(f["xpos"], s[0]["xpos"]) and np.array_equal(bits(d), bits(s[1]))
+
+
+def test_stage_isolation_with_uploaded_planes(oracle_mod, gpu_hip):
+    """Keypoint stages re-run on planes written through the debug hook give the oracle's result
+    for those planes (checks the stages independently of the pyramid kernel)."""
+    img = synth(60, 160, 120)
+    orc = oracle_mod.Oracle(threads=4).run(img)
+    ctx = gpu_hip.Context()
+    ctx.submit(np.zeros_like(img)).wait()
+    for o in range(orc.num_octaves):
+        for l in range(6):
+            ctx.upload_plane(o, 0, l, orc.plane(o, 0, l))
+        for l in range(5):
+            ctx.upload_plane(o, 1, l, orc.plane(o, 1, l))
+    ctx.rerun_keypoint_stages()
+    assert_keypoints_match(orc, ctx)
+
+
+def test_call_sequence_errors(gpu_hip):
+    ctx = gpu_hip.Context()
+    with pytest.raises(gpu_hip.PopsiftHipError) as e:
+        ctx.wait()
+    assert e.value.status == gpu_hip.ERR_STATE
+    with pytest.raises(gpu_hip.PopsiftHipError) as e:
+        gpu_hip.Context(device=99)
+    assert e.value.status == gpu_hip.ERR_INVALID
+    import ctypes as C
+    img = synth(61, 64, 48)
+    ctx.submit(img)
+    nf, nd = ctx.wait()
+    feats = np.zeros(max(nf - 1, 0), gpu_hip.FEATURE_DTYPE)
+    rc = gpu_hip.lib().popsift_hip_fetch(ctx._h, feats.ctypes.data, max(nf - 1, 0), None, 0)
+    assert rc in (gpu_hip.ERR_TOO_SMALL, gpu_hip.ERR_INVALID)
+    rc = gpu_hip.lib().popsift_hip_submit_u8(ctx._h, img.ctypes.data, 64, 48, 10)
+    assert rc == gpu_hip.ERR_INVALID          # pitch < width

@@ -1,0 +1,89 @@
+/*
+ * popsift/features.h -- result containers of the drop-in API.
+ * Replaces features.h:22-96 (Feature, FeaturesBase, FeaturesHost, typedef Features).
+ * Layouts are the reference's: Feature keeps its four Descriptor* which point
+ * into the FeaturesHost's own descriptor array.  FeaturesDev (device-resident
+ * results + brute-force matcher, features.h:98-118) is not part of this build.
+ */
+#pragma once
+
+#include <iostream>
+#include <vector>
+
+#include "sift_constants.h"
+#include "sift_extremum.h"
+
+namespace popsift {
+
+struct Feature {
+    int         debug_octave;
+    float       xpos;
+    float       ypos;
+    float       sigma;
+    int         num_ori;
+    float       orientation[ORIENTATION_MAX_COUNT];
+    Descriptor* desc[ORIENTATION_MAX_COUNT];
+
+    void print(std::ostream& ostr, bool write_as_uchar) const;
+};
+
+std::ostream& operator<<(std::ostream& ostr, const Feature& feature);
+
+class FeaturesBase {
+    int _num_ext;
+    int _num_ori;
+
+public:
+    FeaturesBase() : _num_ext(0), _num_ori(0) {}
+    virtual ~FeaturesBase() {}
+
+    inline int size() const { return _num_ext; }
+    inline int getFeatureCount() const { return _num_ext; }
+    inline int getDescriptorCount() const { return _num_ori; }
+
+    inline void setFeatureCount(int num_ext) { _num_ext = num_ext; }
+    inline void setDescriptorCount(int num_ori) { _num_ori = num_ori; }
+};
+
+class FeaturesHost : public FeaturesBase {
+    Feature*    _ext;
+    Descriptor* _ori;
+
+public:
+    FeaturesHost();
+    FeaturesHost(int num_ext, int num_ori);
+    virtual ~FeaturesHost();
+
+    typedef Feature*       F_iterator;
+    typedef const Feature* F_const_iterator;
+
+    inline F_iterator       begin() { return _ext; }
+    inline F_const_iterator begin() const { return _ext; }
+    inline F_iterator       end() { return &_ext[size()]; }
+    inline F_const_iterator end() const { return &_ext[size()]; }
+
+    /* (re)allocates page-aligned arrays for num_ext features / num_ori descriptors */
+    void reset(int num_ext, int num_ori);
+    /* host-memory registration with the GPU runtime; no-ops here (results are staged
+     * through the context's own pinned buffers) but kept for source compatibility */
+    void pin() {}
+    void unpin() {}
+
+    inline Feature*    getFeatures() { return _ext; }
+    inline Descriptor* getDescriptors() { return _ori; }
+
+    /* one line per (feature, orientation): x y 1/s^2 0 1/s^2 d0 .. d127 */
+    void print(std::ostream& ostr, bool write_as_uchar) const;
+};
+
+typedef FeaturesHost Features;
+
+std::ostream& operator<<(std::ostream& ostr, const FeaturesHost& feature);
+
+/* MatchingMode is not part of this build; the type exists so that code mentioning it compiles */
+class FeaturesDev : public FeaturesBase {
+public:
+    FeaturesDev() {}
+};
+
+}  // namespace popsift

@@ -1,0 +1,267 @@
+/*
+ * PopSift / SiftJob over the HIP C ABI (replaces popsift.cpp:16-318).
+ *
+ * The reference runs ONE pipeline: an upload thread, a compute thread and a single
+ * process-global pyramid.  Here a PopSift object owns a pool of workers -- one per
+ * extraction context, POPSIFT_CONTEXTS_PER_DEVICE contexts on each GPU listed in
+ * POPSIFT_DEVICES -- that pull jobs from one queue (work stealing balances images
+ * of different sizes and GPUs of different load).  Each worker drives its own
+ * popsift_hip_ctx: submit (H2D + every kernel, asynchronous), wait, fetch into the
+ * caller-visible FeaturesHost, fulfil the job's promise.  No collective is needed:
+ * images are independent.
+ */
+#include "popsift/popsift.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+
+#include "popsift_hip.h"
+
+using namespace std;
+
+namespace {
+
+[[noreturn]] void die(const char* file, int line, const std::string& msg)
+{
+    /* the reference's error convention: message on cerr, then exit (debug_macros.h:141-146) */
+    cerr << file << ":" << line << endl << "E    " << msg << endl;
+    exit(-1);
+}
+#define DIE(msg) die(__FILE__, __LINE__, (msg))
+
+popsift_hip_params to_params(const popsift::Config& c)
+{
+    popsift_hip_params p;
+    popsift_hip_default_params(&p);
+    p.octaves = c.octaves;
+    p.levels = c.levels;
+    p.sigma = c.sigma;
+    p.edge_limit = c._edge_limit;
+    p.threshold = c.getThreshold();
+    p.upscale_factor = c.getUpscaleFactor();
+    p.sift_mode = (int)c.getSiftMode();
+    p.gauss_mode = (int)c.getGaussMode();
+    p.desc_mode = (int)c.getDescMode();
+    p.norm_mode = (int)c.getNormMode();
+    p.norm_multi = c.getNormalizationMultiplier();
+    p.max_extrema = c.getMaxExtrema();
+    p.assume_initial_blur = c.hasInitialBlur() ? 1 : 0;
+    p.initial_blur = c.getInitialBlur();
+    p.filter_grid_size = c.getFilterGridSize();
+    return p;
+}
+
+std::vector<int> device_list()
+{
+    int n = 0;
+    if (popsift_hip_device_count(&n) != POPSIFT_HIP_OK || n <= 0) DIE("no usable GPU found");
+    std::vector<int> devs;
+    const char*      e = getenv("POPSIFT_DEVICES");
+    if (!e || !*e || string(e) == "all") {
+        for (int i = 0; i < n; i++) devs.push_back(i);
+        return devs;
+    }
+    stringstream ss(e);
+    string       tok;
+    while (getline(ss, tok, ',')) {
+        const int d = atoi(tok.c_str());
+        if (d < 0 || d >= n) DIE("POPSIFT_DEVICES names a device that does not exist: " + tok);
+        devs.push_back(d);
+    }
+    if (devs.empty()) DIE("POPSIFT_DEVICES is empty");
+    return devs;
+}
+
+int contexts_per_device()
+{
+    const char* e = getenv("POPSIFT_CONTEXTS_PER_DEVICE");
+    const int   k = e ? atoi(e) : 2; /* the reference double-buffers uploads: 2 images in flight */
+    return std::min(std::max(k, 1), 64);
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------------- SiftJob */
+
+SiftJob::SiftJob(int w, int h, const unsigned char* imageData) : _w(w), _h(h), _is_float(false)
+{
+    _f = _p.get_future();
+    _imageData = (unsigned char*)malloc((size_t)w * h);
+    if (_imageData == 0) DIE("Memory limitation: failed to allocate memory for SiftJob");
+    memcpy(_imageData, imageData, (size_t)w * h);
+}
+
+SiftJob::SiftJob(int w, int h, const float* imageData) : _w(w), _h(h), _is_float(true)
+{
+    _f = _p.get_future();
+    _imageData = (unsigned char*)malloc((size_t)w * h * sizeof(float));
+    if (_imageData == 0) DIE("Memory limitation: failed to allocate memory for SiftJob");
+    memcpy(_imageData, imageData, (size_t)w * h * sizeof(float));
+}
+
+SiftJob::~SiftJob() { free(_imageData); }
+
+void SiftJob::setFeatures(popsift::FeaturesBase* f) { _p.set_value(f); }
+
+popsift::FeaturesHost* SiftJob::get() { return getHost(); }
+popsift::FeaturesBase* SiftJob::getBase() { return _f.get(); }
+popsift::FeaturesHost* SiftJob::getHost() { return dynamic_cast<popsift::FeaturesHost*>(_f.get()); }
+popsift::FeaturesDev*  SiftJob::getDev() { return dynamic_cast<popsift::FeaturesDev*>(_f.get()); }
+
+/* ------------------------------------------------------------------------- PopSift */
+
+PopSift::PopSift(const popsift::Config& config, popsift::Config::ProcessingMode mode, ImageMode imode)
+    : _image_mode(imode)
+{
+    if (mode != popsift::Config::ExtractingMode)
+        DIE("MatchingMode (device-resident features + matcher) is not part of this build");
+    configure(config, true);
+}
+
+PopSift::PopSift(ImageMode imode) : _image_mode(imode) {}
+
+PopSift::~PopSift()
+{
+    /* the reference leaks its threads if uninit() was forgotten (popsift.cpp:59-61); be kind */
+    if (_started && !_stopped) uninit();
+}
+
+bool PopSift::configure(const popsift::Config& config, bool /*force*/)
+{
+    std::lock_guard<std::mutex> lk(_mtx);
+    if (_started) return false; /* popsift.cpp:65-67: not after the pyramid exists */
+    _config = config;
+    _config.levels = max(2, config.levels); /* popsift.cpp:71 */
+    /* validate now, fatally, like init_filter does (gauss_filter.cu:131-144) */
+    if (_config.sigma > 2.0f) DIE("Sigma > 2.0 is not supported.");
+    if (_config.levels > GAUSS_LEVELS - 3) DIE("More than 9 levels are not supported.");
+    if (_config.getGaussMode() != popsift::Config::VLFeat_Compute &&
+        _config.getGaussMode() != popsift::Config::OpenCV_Compute)
+        DIE("this build implements the Gauss modes 'vlfeat' and 'opencv' only");
+    if (_config.getDescMode() != popsift::Config::Loop) DIE("this build implements the descriptor mode 'loop' only");
+    if (_config.getScalingMode() != popsift::Config::ScaleDefault) DIE("ScaleDirect is not supported");
+    _shadow_config = _config;
+    return true;
+}
+
+/* popsift.cpp:89-120: the first image fixes the octave count for every context */
+void PopSift::start_workers(int w, int h)
+{
+    if (_config.octaves < 0) {
+        const float scaleFactor = 1.0f / powf(2.0f, -_config.getUpscaleFactor());
+        _config.octaves = max(int(floorf(logf((float)min(w, h)) / logf(2.0f)) - 3.0f + scaleFactor), 1);
+    }
+    const popsift_hip_params p = to_params(_config);
+    const std::vector<int>   devs = device_list();
+    const int                per = contexts_per_device();
+    for (int k = 0; k < per; k++) {
+        for (int d : devs) {
+            Worker* wk = new Worker;
+            wk->device = d;
+            const int rc = popsift_hip_ctx_create(d, &p, &wk->ctx);
+            if (rc != POPSIFT_HIP_OK) DIE(string("cannot create extraction context: ") + popsift_hip_strerror(rc));
+            _workers.push_back(wk);
+        }
+    }
+    for (Worker* wk : _workers) wk->thread = std::thread(&PopSift::worker_loop, this, wk);
+    _started = true;
+}
+
+void PopSift::worker_loop(Worker* me)
+{
+    for (;;) {
+        SiftJob* job;
+        {
+            std::unique_lock<std::mutex> lk(_mtx);
+            _cv.wait(lk, [&] { return !_queue.empty(); });
+            job = _queue.front();
+            if (job == 0) return; /* shutdown marker stays for the other workers */
+            _queue.pop();
+        }
+        int rc;
+        if (job->isFloat())
+            rc = popsift_hip_submit_f32(me->ctx, (const float*)job->getImageData(), job->getWidth(), job->getHeight(),
+                                        job->getWidth());
+        else
+            rc = popsift_hip_submit_u8(me->ctx, job->getImageData(), job->getWidth(), job->getHeight(), job->getWidth());
+        int nf = 0, nd = 0;
+        if (rc == POPSIFT_HIP_OK) rc = popsift_hip_wait(me->ctx, &nf, &nd);
+        if (rc != POPSIFT_HIP_OK) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
+
+        popsift::FeaturesHost* features = new popsift::FeaturesHost(nf, nd);
+        if (nd == 0) cerr << "Warning: no descriptors extracted" << endl; /* sift_desc.cu:88-92 */
+        if (nf > 0) {
+            std::vector<popsift_hip_feature> pod((size_t)nf);
+            rc = popsift_hip_fetch(me->ctx, pod.data(), pod.size(), (float*)features->getDescriptors(),
+                                   (size_t)nd * 128);
+            if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
+            popsift::Feature*    out = features->getFeatures();
+            popsift::Descriptor* base = features->getDescriptors();
+            for (int i = 0; i < nf; i++) {
+                const popsift_hip_feature& s = pod[(size_t)i];
+                popsift::Feature&          f = out[i];
+                f.debug_octave = s.debug_octave;
+                f.xpos = s.xpos;
+                f.ypos = s.ypos;
+                f.sigma = s.sigma;
+                f.num_ori = s.num_ori;
+                for (int k = 0; k < ORIENTATION_MAX_COUNT; k++) {
+                    f.orientation[k] = s.orientation[k];
+                    f.desc[k] = s.desc_idx[k] >= 0 ? base + s.desc_idx[k] : 0;
+                }
+            }
+        }
+        job->setFeatures(features);
+    }
+}
+
+void PopSift::uninit()
+{
+    {
+        std::lock_guard<std::mutex> lk(_mtx);
+        if (_stopped) return;
+        _stopped = true;
+        _queue.push(0);
+    }
+    _cv.notify_all();
+    for (Worker* wk : _workers) {
+        if (wk->thread.joinable()) wk->thread.join();
+        popsift_hip_ctx_destroy(wk->ctx);
+        delete wk;
+    }
+    _workers.clear();
+}
+
+SiftJob* PopSift::enqueue(int w, int h, const unsigned char* imageData)
+{
+    if (_image_mode != ByteImages)
+        DIE("Image mode error: cannot load byte images into a PopSift pipeline configured for float images");
+    SiftJob* job = new SiftJob(w, h, imageData);
+    {
+        std::lock_guard<std::mutex> lk(_mtx);
+        if (_stopped) DIE("enqueue() after uninit()");
+        if (!_started) start_workers(w, h);
+        _queue.push(job);
+    }
+    _cv.notify_one();
+    return job;
+}
+
+SiftJob* PopSift::enqueue(int w, int h, const float* imageData)
+{
+    if (_image_mode != FloatImages)
+        DIE("Image mode error: cannot load float images into a PopSift pipeline configured for byte images");
+    SiftJob* job = new SiftJob(w, h, imageData);
+    {
+        std::lock_guard<std::mutex> lk(_mtx);
+        if (_stopped) DIE("enqueue() after uninit()");
+        if (!_started) start_workers(w, h);
+        _queue.push(job);
+    }
+    _cv.notify_one();
+    return job;
+}

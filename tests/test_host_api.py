@@ -79,7 +79,15 @@ def test_demo_program_matches_c_abi(gpu_hip, tmp_path):
                 want.append(np.concatenate([[f["xpos"], f["ypos"], 1.0 / f["sigma"] ** 2], desc[f["desc_idx"][k]]]))
         want = np.array(want)
         got = block[:, [0, 1, 2] + list(range(5, 133))]
-        key = lambda a: a[np.lexsort((a[:, 5], a[:, 4], a[:, 3], a[:, 2], a[:, 1], a[:, 0]))]
-        np.testing.assert_allclose(key(got)[:, :3], key(want)[:, :3], rtol=2e-5)
-        np.testing.assert_allclose(key(got)[:, 3:], key(want)[:, 3:], atol=6e-4)  # printed with 3 digits
+        assert got.shape == want.shape
+        # printed with 6 (positions) / 3 (descriptor) significant digits: match rows by nearest position
+        used = np.zeros(len(want), bool)
+        for g in got:
+            d = np.abs(want[:, 0] - g[0]) + np.abs(want[:, 1] - g[1]) + np.abs(want[:, 3:] - g[3:]).max(1)
+            d[used] = np.inf
+            j = int(np.argmin(d))
+            used[j] = True
+            np.testing.assert_allclose(g[:3], want[j, :3], rtol=2e-5)
+            np.testing.assert_allclose(g[3:], want[j, 3:], atol=6e-4)
+        assert used.all()
     assert ofs == len(rows)

@@ -80,6 +80,8 @@ struct popsift_hip_ctx {
     PyrDesc*  h_pd = nullptr; /* pinned staging for d_pd */
     int2*     d_cand = nullptr;
     int       cand_cap = 0;
+    int*      d_partial = nullptr; /* one partial sum per scan chunk */
+    size_t    partial_cap = 0;
 
     /* profiling */
     int                    profile = 0;
@@ -263,6 +265,7 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
         if (int rc = grow(c, &c->d_feats, &cap2, need_ext)) return rc;
         c->ext_cap = need_ext;
     }
+    if (int rc = grow(c, &c->d_partial, &c->partial_cap, need_ext / scan_chunk() + 2)) return rc;
     /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
         return rc;
@@ -357,7 +360,9 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
     HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_iext, c->stream));
     HIP_TRY(c, launch_orientation(c->d_pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 8192, c->stream));
-    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->desc_cap, c->stream));
+    const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
+    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->desc_cap,
+                           c->stream));
     HIP_TRY(c, launch_descriptors(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 16384,
                                   c->stream));
     HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
@@ -431,6 +436,17 @@ int finish(popsift_hip_ctx* c)
         HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     }
     popsift_hip_report& r = c->rep;
+    /* per-octave descriptor counts from the octave start offsets the scan left (dct.ori_ps / ori_ct) */
+    int next = c->h_ct->ori_total;
+    for (int o = PS_MAX_OCT - 1; o >= 0; o--) {
+        if (c->h_ct->ext_ct[o] > 0) {
+            c->h_ct->ori_ct[o] = next - c->h_ct->ori_ps[o];
+            next = c->h_ct->ori_ps[o];
+        } else {
+            c->h_ct->ori_ct[o] = 0;
+            c->h_ct->ori_ps[o] = next;
+        }
+    }
     for (int o = 0; o < PS_MAX_OCT; o++) {
         r.ext_ct[o] = c->h_ct->ext_ct[o];
         r.ori_ct[o] = c->h_ct->ori_ct[o];
@@ -591,6 +607,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_pd) (void)hipFree(c->d_pd);
     if (c->h_pd) (void)hipHostFree(c->h_pd);
     if (c->d_cand) (void)hipFree(c->d_cand);
+    if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->h_ct) (void)hipHostFree(c->h_ct);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

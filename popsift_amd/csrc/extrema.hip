@@ -260,7 +260,19 @@ __device__ bool refine(const DogView& dog, const SiftConsts& sc, int x, int y, i
  */
 constexpr int DET_W = 62;
 constexpr int DET_RH = 32;
-constexpr int DET_Q = 1024; /* per-wave candidate queue (entries) */
+
+/* neighbour lane values through DPP wave shifts (VALU rate) instead of ds_bpermute (LDS
+ * crossbar); lanes 0 / 63 have no source and keep their own value, like __shfl_up/_down */
+__device__ __forceinline__ float lane_left(float v)
+{
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right(float v)
+{
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
 
 template <int NP>
 struct RowRed {
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
      * per ~DET_Q entries: a returning atomic on a single hot counter saturates
      * at ~90 per microsecond (MI355X_MICROARCH.md "dequeue"), which made a
      * per-row atomic the whole cost of this kernel. */
+    constexpr int   DET_Q = (128 * LEVELS > 512) ? 128 * LEVELS : 512; /* >= 2 rows' worth of hits */
     __shared__ int2 s_queue[4][DET_Q];
     int2*           queue = s_queue[threadIdx.x >> 6];
     int             n_buf = 0;
@@ -321,13 +334,18 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
     RowRed<NP>    A, B, C;
     float         vB[NP], smx[NP], smn[NP];
 
-    auto load_row = [&](int y, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
+    /* raw loads of one row of all NP planes (issued early, consumed one iteration later) */
+    auto fetch_row = [&](int y, float* raw) {
         const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
+        for (int z = 0; z < NP; z++) raw[z] = p[z * od.plane_stride];
+    };
+    auto reduce_row = [&](const float* raw, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
+#pragma unroll
         for (int z = 0; z < NP; z++) {
-            const float c = p[z * od.plane_stride];
-            const float l = __shfl_up(c, 1);
-            const float r = __shfl_down(c, 1);
+            const float c = raw[z];
+            const float l = lane_left(c);
+            const float r = lane_right(c);
             v[z] = c;
             sx_[z] = fmaxf(l, r);
             sn_[z] = fminf(l, r);
@@ -335,14 +353,22 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             R.mn[z] = fminf(sn_[z], c);
         }
     };
+    float raw_next[NP];
     {
-        float tv[NP], ts[NP], tn[NP];
-        load_row(yb - 1, A, tv, ts, tn);
-        load_row(yb, B, vB, smx, smn);
+        float tv[NP], ts[NP], tn[NP], ra[NP], rb[NP];
+        fetch_row(yb - 1, ra);
+        fetch_row(yb, rb);
+        fetch_row(yb + 1, raw_next);
+        reduce_row(ra, A, tv, ts, tn);
+        reduce_row(rb, B, vB, smx, smn);
     }
     for (int y = yb; y <= ye; y++) {
-        float vC[NP], cmx[NP], cmn[NP];
-        load_row(y + 1, C, vC, cmx, cmn);
+        float vC[NP], cmx[NP], cmn[NP], raw_cur[NP];
+#pragma unroll
+        for (int z = 0; z < NP; z++) raw_cur[z] = raw_next[z];
+        /* software pipeline: row y+2 is requested before row y+1 is consumed */
+        if (y + 2 <= ye + 1) fetch_row(y + 2, raw_next);
+        reduce_row(raw_cur, C, vC, cmx, cmn);
         bool row_ok = lane_ok;
         if (MODE == POPSIFT_HIP_SIFT_OPENCV) row_ok = row_ok && (y >= 5 && y < h - 5);
         /* full 3x3 extremes of every plane (centre column included) */

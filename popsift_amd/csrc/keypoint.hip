@@ -222,93 +222,116 @@ __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__
 
 /* ------------------------------------------------------------------- scan */
 
-__global__ __launch_bounds__(1024) void k_scan(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                               Counters* __restrict__ ct, Ext* __restrict__ ext,
-                                               int* __restrict__ map, int desc_cap)
-{
-    const int n_oct = pdp->n_oct;
-    __shared__ int s_wsum[16];
-    __shared__ int s_carry;
-    __shared__ int s_ps[PS_MAX_OCT + 1];
-    const int      tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+/*
+ * Exclusive prefix sum of num_ori over all extrema -> idx_ori, the reverse map
+ * descriptor -> extremum, and the totals (replaces ori_prefix_sum's single
+ * 32x32 block looping over everything, s_orientation.cu:303-345).  Two launches:
+ * k_scan_local scans 2048-extrema chunks and leaves one partial per chunk;
+ * k_scan_apply adds the sum of the preceding partials (<= 440 values for the
+ * default 9 x 100000 capacity, summed redundantly per workgroup) and writes the
+ * map and the counters.
+ */
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = 256 * SCAN_ITEMS;
 
+__device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConsts& sc, int n_oct)
+{
+    int acc = 0;
+    for (int o = 0; o < n_oct; o++) acc += min(ct->ext_ct[o], sc.max_extrema);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                    const Counters* __restrict__ ct, Ext* __restrict__ ext,
+                                                    int* __restrict__ partial)
+{
+    __shared__ int s_wsum[4];
+    const int      total = clamped_total(ct, sc, pdp->n_oct);
+    const int      base = blockIdx.x * SCAN_CHUNK;
+    if (base >= total) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g0 = base + tid * SCAN_ITEMS;
+    int       cnt[SCAN_ITEMS];
+    int       self = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        cnt[k] = (g0 + k < total) ? ext[g0 + k].num_ori : 0;
+        self += cnt[k];
+    }
+    int incl = self;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int v = __shfl_up(incl, s);
+        if (lane >= s) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += s_wsum[w];
+    int excl = woff + incl - self;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (g0 + k < total) ext[g0 + k].idx_ori = excl; /* chunk-local for now */
+        excl += cnt[k];
+    }
+    if (tid == 255) partial[blockIdx.x] = excl;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                    Counters* __restrict__ ct, Ext* __restrict__ ext,
+                                                    const int* __restrict__ partial, int* __restrict__ map,
+                                                    int desc_cap)
+{
+    __shared__ int s_red[4];
+    __shared__ int s_ps[PS_MAX_OCT + 1];
+    const int      n_oct = pdp->n_oct;
+    const int      tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         int acc = 0;
         for (int o = 0; o < PS_MAX_OCT; o++) {
-            const int c = (o < n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
-            ct->ext_ct[o] = c; /* the reference clamps with atomicMin, s_extrema.cu:558 */
-            ct->ext_ps[o] = acc;
             s_ps[o] = acc;
-            acc += c;
+            acc += (o < n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
         }
         s_ps[PS_MAX_OCT] = acc;
-        ct->ext_total = acc;
-        s_carry = 0;
     }
     __syncthreads();
     const int total = s_ps[PS_MAX_OCT];
+    const int base = blockIdx.x * SCAN_CHUNK;
+    if (base >= total && blockIdx.x != 0) return;
 
-    constexpr int ITEMS = 16; /* consecutive extrema per lane */
-    for (int base = 0; base < total; base += 1024 * ITEMS) {
-        const int g0 = base + tid * ITEMS;
-        int       cnt[ITEMS];
-        int       self = 0;
+    /* offset of this chunk = sum of the partials of all preceding chunks */
+    int acc = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) acc += partial[b];
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            cnt[k] = (g0 + k < total) ? ext[g0 + k].num_ori : 0;
-            self += cnt[k];
-        }
-        /* inclusive wave64 scan of the per-lane sums */
-        int incl = self;
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) s_red[wave] = acc;
+    __syncthreads();
+    const int offset = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+
+    const int g0 = base + tid * SCAN_ITEMS;
 #pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const int v = __shfl_up(incl, s);
-            if (lane >= s) incl += v;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int g = g0 + k;
+        if (g < total) {
+            const int idx = ext[g].idx_ori + offset;
+            const int n = ext[g].num_ori;
+            ext[g].idx_ori = idx;
+            for (int q = 0; q < n; q++)
+                if (idx + q < desc_cap) map[idx + q] = g;
+            /* first extremum of an octave: start of that octave's descriptors (dct.ori_ps) */
+            for (int o = 0; o < n_oct; o++)
+                if (g == s_ps[o] && s_ps[o + 1] > s_ps[o]) ct->ori_ps[o] = idx;
         }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        if (wave == 0) {
-            int v = (lane < 16) ? s_wsum[lane] : 0;
-            int inc2 = v;
-#pragma unroll
-            for (int s = 1; s < 16; s <<= 1) {
-                const int u = __shfl_up(inc2, s);
-                if (lane >= s) inc2 += u;
-            }
-            if (lane < 16) s_wsum[lane] = inc2 - v; /* exclusive */
-        }
-        __syncthreads();
-        const int carry = s_carry;
-        int       excl = carry + s_wsum[wave] + incl - self;
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            if (g0 + k < total) {
-                ext[g0 + k].idx_ori = excl;
-                for (int q = 0; q < cnt[k]; q++)
-                    if (excl + q < desc_cap) map[excl + q] = g0 + k;
-            }
-            excl += cnt[k];
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry = excl;
-        __syncthreads();
     }
-
-    if (tid == 0) {
-        const int ori_total = s_carry;
-        /* per-octave orientation counts (s_orientation.cu:319-339) */
-        int acc = 0;
+    const int nb = (total + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (tid == 0 && ((int)blockIdx.x == nb - 1 || (nb == 0 && blockIdx.x == 0))) {
+        ct->ori_total = (nb > 0) ? offset + partial[blockIdx.x] : 0;
+        ct->ext_total = total;
         for (int o = 0; o < PS_MAX_OCT; o++) {
-            int c = 0;
-            if (o < n_oct && ct->ext_ct[o] > 0) {
-                const int fe = s_ps[o], le = s_ps[o + 1] - 1;
-                c = ext[le].idx_ori + ext[le].num_ori - ext[fe].idx_ori;
-            }
-            ct->ori_ct[o] = c;
-            ct->ori_ps[o] = acc;
-            acc += c;
+            /* the reference clamps with atomicMin in the extrema kernel, s_extrema.cu:558 */
+            ct->ext_ct[o] = (o < n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
+            ct->ext_ps[o] = s_ps[o];
         }
-        ct->ori_total = ori_total;
     }
 }
 
@@ -356,6 +379,14 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
         wave_lds_sync();
 
         const float SBP = fabsf(DESC_MAGNIFY * sigma);
+        /* Each cell word packs two 32-bit fixed-point sums: low = share of orientation bin b, high =
+         * share of bin b+1 coming from samples whose lower bin is b, so ONE 64-bit LDS atomic per cell
+         * serves both bins of a sample.  The scale 2^fbits keeps the worst-case low sum below 2^32
+         * (no carry into the high half): a sample weighs <= 361 (|gradient| of a 0..255 plane, unit
+         * window weights) and a cell sees at most (2.83*SBP+1)^2 pixels. */
+        const float cell_px = (2.83f * SBP + 1.0f) * (2.83f * SBP + 1.0f);
+        const int   fbits = min(max(31 - (int)ceilf(log2f(361.0f * cell_px)), 2), 20);
+        const float fscale = scalbnf(1.0f, fbits);
         if (SBP != 0.0f) {
             float sin_t, cos_t;
             sincosf(ang, &sin_t, &cos_t);
@@ -397,7 +428,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
                     const float ffo = floorf(tth);
                     const float do0 = tth - ffo;
                     const int   fo0 = (int)ffo;
-                    const int   b0 = fo0 & 7, b1 = (fo0 + 1) & 7;
+                    const int   b0 = fo0 & 7;
 
                     /* cell centres sit at integer tu, tv in 0..3; the sample feeds cells
                      * (cx0, cx0+1) x (cy0, cy0+1) with weights (1-fx, fx) x (1-fy, fy)
@@ -414,14 +445,14 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
                     const int   ix0 = max(cx0, 0), ix1 = min(cx0 + 1, 3);
                     const int   iy0 = max(cy0, 0), iy1 = min(cy0 + 1, 3);
                     const float w1 = do0, w0 = 1.0f - do0;
-#define PS_CELL(IY, IX, WGT)                                                \
-    {                                                                       \
-        const float wgt = (WGT);                                            \
-        if (wgt > 0.0f) {                                                   \
-            fix64* cell = &hist[(((IY) << 2) + (IX)) << 3];                 \
-            atomicAdd(&cell[b0], to_fix(w0 * wgt));                         \
-            atomicAdd(&cell[b1], to_fix(w1 * wgt));                         \
-        }                                                                   \
+#define PS_CELL(IY, IX, WGT)                                                              \
+    {                                                                                     \
+        const float wgt = (WGT) * fscale;                                                 \
+        if (wgt > 0.0f) {                                                                 \
+            const unsigned int lo = (unsigned int)(w0 * wgt + 0.5f);                      \
+            const unsigned int hi = (unsigned int)(w1 * wgt + 0.5f);                      \
+            atomicAdd(&hist[((((IY) << 2) + (IX)) << 3) + b0], ((fix64)hi << 32) | lo);  \
+        }                                                                                 \
     }
                     PS_CELL(iy0, ix0, wy0 * wx0)
                     PS_CELL(iy0, ix1, wy0 * wx1)
@@ -434,13 +465,16 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
         wave_lds_sync();
 
         /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
-        fix64 a0 = 0ull, a1 = 0ull;
+        /* bin b of a cell = low half of word b + high half of word b-1 (mod 8), over the copies */
+        fix64     a0 = 0ull, a1 = 0ull;
+        const int prevw = (lane & ~7) | ((lane + 7) & 7);
 #pragma unroll
         for (int k = 0; k < DCOPY; k++) {
-            a0 += hall[k * 128 + lane];
-            a1 += hall[k * 128 + lane + 64];
+            a0 += (hall[k * 128 + lane] & 0xffffffffull) + (hall[k * 128 + prevw] >> 32);
+            a1 += (hall[k * 128 + lane + 64] & 0xffffffffull) + (hall[k * 128 + prevw + 64] >> 32);
         }
-        float v0 = from_fix(a0), v1 = from_fix(a1);
+        const float inv_scale = scalbnf(1.0f, -fbits);
+        float       v0 = (float)a0 * inv_scale, v1 = (float)a1 * inv_scale;
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
 #pragma unroll
@@ -503,12 +537,15 @@ hipError_t launch_orientation(const PyrDesc* pd, const SiftConsts& sc, const Cou
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* map, int desc_cap,
-                       hipStream_t s)
+hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
+                       int* map, int desc_cap, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, pd, sc, ct, ext, map, desc_cap);
+    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, desc_cap);
     return hipGetLastError();
 }
+
+int scan_chunk() { return SCAN_CHUNK; }
 
 hipError_t launch_descriptors(const PyrDesc* pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
                               const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)

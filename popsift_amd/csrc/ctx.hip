@@ -253,8 +253,10 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     for (int o = 0; o < n_oct; o++) {
         OctDesc& od = pd.o[o];
         od.data = p;
+        od.data_off = p - c->d_arena;
         p += od.plane_stride * c->L;
         od.dog = p;
+        od.dog_off = p - c->d_arena;
         p += od.plane_stride * (c->L - 1);
     }
     const size_t need_ext = (size_t)n_oct * (size_t)c->sc.max_extrema;
@@ -358,12 +360,12 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
-    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_iext, c->stream));
-    HIP_TRY(c, launch_orientation(c->d_pd, c->sc, c->d_ct, c->d_iext, c->d_ext, 8192, c->stream));
+    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_iext, c->stream));
+    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_iext, c->d_ext, 8192, c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->desc_cap,
                            c->stream));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 16384,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 16384,
                                   c->stream));
     HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));

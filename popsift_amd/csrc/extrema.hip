@@ -281,8 +281,9 @@ struct RowRed {
 
 /* LEVELS = DoG search levels; NP = LEVELS + 2 DoG planes */
 template <int MODE, int LEVELS>
-__global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                Counters* __restrict__ ct, int2* __restrict__ cand, int cand_cap)
+__global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
+                                                SiftConsts sc, Counters* __restrict__ ct, int2* __restrict__ cand,
+                                                int cand_cap)
 {
     const int lane = threadIdx.x & 63;
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
     };
 
     constexpr int NP = LEVELS + 2;
-    const float*  base = od.dog + xc;
+    const float*  base = arena + od.dog_off + xc;
     RowRed<NP>    A, B, C;
     float         vB[NP], smx[NP], smn[NP];
 
@@ -408,9 +409,10 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
 
 /* Refinement of the compacted candidates: one lane per candidate, dense waves. */
 template <int MODE>
-__global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                Counters* __restrict__ ct, const int2* __restrict__ cand,
-                                                int cand_cap, InitExt* __restrict__ iext)
+__global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
+                                                SiftConsts sc, Counters* __restrict__ ct,
+                                                const int2* __restrict__ cand, int cand_cap,
+                                                InitExt* __restrict__ iext)
 {
     const int lane = threadIdx.x & 63;
     const int L = pdp->L;
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
             o = cd.y >> 8;
             const OctDesc* od = &pdp->o[o];
             DogView        dog;
-            dog.base = od->dog;
+            dog.base = arena + od->dog_off;
             dog.ps = od->plane_stride;
             dog.w = od->w;
             dog.h = od->h;
@@ -463,38 +465,38 @@ int extrema_units(int w, int h)
 }
 
 template <int MODE>
-static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, int2* cand,
-                          int cand_cap, hipStream_t s)
+static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
+                          Counters* ct, int2* cand, int cand_cap, hipStream_t s)
 {
     const dim3 grid((pd.total_tiles + 3) / 4), block(256);
     switch (pd.levels) {
 #define PS_LV(N)                                                                                   \
     case N:                                                                                        \
-        hipLaunchKernelGGL((k_detect<MODE, N>), grid, block, 0, s, d_pd, sc, ct, cand, cand_cap); \
+        hipLaunchKernelGGL((k_detect<MODE, N>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap); \
         break;
         PS_LV(2) PS_LV(3) PS_LV(4) PS_LV(5) PS_LV(6) PS_LV(7) PS_LV(8) PS_LV(9)
 #undef PS_LV
     }
 }
 
-hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, int2* cand,
-                          int cand_cap, InitExt* iext, hipStream_t s)
+hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
+                          Counters* ct, int2* cand, int cand_cap, InitExt* iext, hipStream_t s)
 {
     if (pd.total_tiles <= 0) return hipSuccess;
     if (pd.levels < 2 || pd.levels > 9) return hipErrorInvalidValue;
     const dim3 block(256), rgrid(1024);
     switch (sc.sift_mode) {
     case POPSIFT_HIP_SIFT_OPENCV:
-        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, sc, ct, cand, cand_cap, s);
-        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV>), rgrid, block, 0, s, d_pd, sc, ct, cand, cand_cap, iext);
+        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, arena, sc, ct, cand, cand_cap, s);
+        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     case POPSIFT_HIP_SIFT_VLFEAT:
-        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, sc, ct, cand, cand_cap, s);
-        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT>), rgrid, block, 0, s, d_pd, sc, ct, cand, cand_cap, iext);
+        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, arena, sc, ct, cand, cand_cap, s);
+        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     default:
-        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, sc, ct, cand, cand_cap, s);
-        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT>), rgrid, block, 0, s, d_pd, sc, ct, cand, cand_cap, iext);
+        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, arena, sc, ct, cand, cand_cap, s);
+        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     }
     return hipGetLastError();

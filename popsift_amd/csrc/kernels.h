@@ -30,16 +30,16 @@ hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* 
 
 /* extrema.hip */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */
-hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, int2* cand,
+hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, int2* cand,
                           int cand_cap, InitExt* iext, hipStream_t s);
 
 /* keypoint.hip */
-hipError_t launch_orientation(const PyrDesc* d_pd, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
+hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
                               Ext* ext, int blocks, hipStream_t s);
 int        scan_chunk(); /* extrema per scan workgroup */
 hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
                        int* map, int desc_cap, hipStream_t s);
-hipError_t launch_descriptors(const PyrDesc* d_pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
+hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, const Counters* ct, const Ext* ext,
                               const int* map, float* desc, int desc_cap, int blocks, hipStream_t s);
 hipError_t launch_prep(const SiftConsts& sc, const Counters* ct, const Ext* ext, popsift_hip_feature* feats,
                        int desc_cap, int blocks, hipStream_t s);

@@ -90,7 +90,8 @@ __device__ __forceinline__ void get_gradiant(float& grad, float& theta, int x, i
 
 /* ------------------------------------------------------------ orientation */
 
-__global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+__global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__ pdp,
+                                                     const float* __restrict__ arena, SiftConsts sc,
                                                      const Counters* __restrict__ ct,
                                                      const InitExt* __restrict__ iext, Ext* __restrict__ ext)
 {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__
         const OctDesc* od = &pdp->o[o];
         const int      w = od->w, h = od->h, pitch = od->pitch;
         const int      lvl = min(max(ie.lpos, 0), L - 1);
-        const float*   layer = od->data + lvl * od->plane_stride;
+        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
 
         if (lane < PS_ORI_NBINS) hist[lane] = 0ull;
         wave_lds_sync();
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__
             const int    row = (int)(((float)i + 0.5f) * inv_wx);
             const int    yy = row + ymin;
             const int    xx = i - row * wx + xmin;
-            const float* c = layer + (size_t)yy * pitch + xx;
+            const float* c = layer + (__mul24(yy, pitch) + xx);
             const float  gdx = c[1] - c[-1];
             const float  gdy = c[pitch] - c[-pitch];
             const float  grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
@@ -337,6 +338,28 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
 
 /* ------------------------------------------------------------- descriptor */
 
+/* atan2(y, x) * 4/pi in (-4, 4]: octant reduction + odd degree-11 minimax polynomial of
+ * atan(r) * 4/pi on [0, 1] (max error 2.2e-6 bins = 1.7e-6 rad, fitted offline), v_rcp instead of
+ * a division.  Only used for the descriptor's SOFT orientation binning, which is continuous in
+ * the angle (the reference uses fast intrinsics there too, s_desc_loop.cu:48,97). */
+__device__ __forceinline__ float atan2_bins(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float       r = mn * __builtin_amdgcn_rcpf(mx);
+    r = (mx == 0.0f) ? 0.0f : r;
+    const float s = r * r;
+    float       p = fmaf(-0.01492126751691103f, s, 0.06703268736600876f);
+    p = fmaf(p, s, -0.14823880791664124f);
+    p = fmaf(p, s, 0.24642325937747955f);
+    p = fmaf(p, s, -0.42350852489471436f);
+    p = fmaf(p, s, 1.2732105255126953f);
+    float t = p * r;
+    t = (ay > ax) ? 2.0f - t : t;
+    t = (x < 0.0f) ? 4.0f - t : t;
+    return (y < 0.0f) ? -t : t;
+}
+
 /*
  * One wave per (extremum, orientation), four per workgroup, no workgroup
  * barrier.  The reference gives every one of the 16 cells its own warp, which
@@ -347,22 +370,27 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
  * a different summation order.  The 128-bin histogram lives in LDS (per wave),
  * is normalised in registers and leaves as two coalesced 256 B rows.
  */
-__global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                    const Counters* __restrict__ ct, const Ext* __restrict__ ext,
-                                                    const int* __restrict__ map, float* __restrict__ desc,
-                                                    int desc_cap)
+__global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
+                                                       const float* __restrict__ arena, SiftConsts sc,
+                                                       const Counters* __restrict__ ct, const Ext* __restrict__ ext,
+                                                       const int* __restrict__ map, float* __restrict__ desc,
+                                                       int desc_cap)
 {
     /* DCOPY private copies of the histogram per wave: neighbouring lanes sample neighbouring
      * pixels, which mostly fall into the same cell and orientation bin; spreading them over
      * copies by lane cuts the same-address serialisation of the LDS atomics */
-    constexpr int    DCOPY = 4;
+    constexpr int    DCOPY = 2;
+    constexpr int    MAXROWS = 256; /* patch rows handled by the span path */
     __shared__ fix64 s_hist[4][DCOPY][128];
+    __shared__ int   s_start[4][MAXROWS + 1]; /* flat index of the first sample of each patch row */
+    __shared__ short s_lo[4][MAXROWS];        /* first column of each patch row's span */
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fix64*           hist = s_hist[wave][lane & (DCOPY - 1)];
     fix64*           hall = s_hist[wave][0];
+    int*             rstart = s_start[wave];
+    short*           rlo = s_lo[wave];
     const int        total = min(ct->ori_total, desc_cap);
     const int        L = pdp->L;
-    const float      M_4RPI = 4.0f / F_PI;
 
     for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
         const Ext*     e = ext + map[d];
@@ -372,11 +400,10 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
         const OctDesc* od = &pdp->o[e->octave];
         const int      width = od->w, height = od->h, pitch = od->pitch;
         const int      lvl = min(max(e->lpos, 0), L - 1);
-        const float*   layer = od->data + lvl * od->plane_stride;
+        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
 
 #pragma unroll
         for (int k = 0; k < 2 * DCOPY; k++) hall[lane + 64 * k] = 0ull;
-        wave_lds_sync();
 
         const float SBP = fabsf(DESC_MAGNIFY * sigma);
         /* Each cell word packs two 32-bit fixed-point sums: low = share of orientation bin b, high =
@@ -401,34 +428,95 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
             const int   ymax = min(height - 2, (int)floorf(y + ext_r) + 1);
             const int   wx = xmax - xmin + 1;
             const int   hy = ymax - ymin + 1;
-            const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
+
+            /* Row spans.  The samples that count lie in the square |u|,|v| < 2.5 (cell units, rotated
+             * by ang), which fills only 1/(|cos|+|sin|)^2 = 50..100 % of its bounding box.  Per patch
+             * row the square cuts out ONE column interval; the rows' intervals are laid end to end
+             * (prefix sum) and the wave walks that flat list, so nearly every lane holds a sample
+             * that passes the exact test below.  Intervals are widened by a pixel: they only have
+             * to be a superset. */
+            int T = 0;
+            if (wx > 0 && hy > 0 && hy <= MAXROWS) {
+                const float inv_c = (fabsf(crsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(crsbp) : 0.0f;
+                const float inv_s = (fabsf(srsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(srsbp) : 0.0f;
+                int         carry = 0;
+                for (int r0 = 0; r0 < hy; r0 += 64) {
+                    const int r = r0 + lane;
+                    int       len = 0, jlo = xmin;
+                    if (r < hy) {
+                        const float dy = (float)(ymin + r) - y;
+                        const float a = srsbp * dy, b = crsbp * dy;
+                        float       lo = -1e30f, hi = 1e30f;
+                        bool        ok = true;
+                        if (inv_c != 0.0f) { /* |crsbp*dx + a| < 2.5 */
+                            const float t0 = (-2.5f - a) * inv_c, t1 = (2.5f - a) * inv_c;
+                            lo = fminf(t0, t1);
+                            hi = fmaxf(t0, t1);
+                        } else {
+                            ok = fabsf(a) < 2.5f;
+                        }
+                        if (inv_s != 0.0f) { /* |b - srsbp*dx| < 2.5 */
+                            const float t0 = (b - 2.5f) * inv_s, t1 = (b + 2.5f) * inv_s;
+                            lo = fmaxf(lo, fminf(t0, t1));
+                            hi = fminf(hi, fmaxf(t0, t1));
+                        } else {
+                            ok = ok && (fabsf(b) < 2.5f);
+                        }
+                        jlo = max(xmin, (int)floorf(x + lo - 0.01f));
+                        const int jhi = min(xmax, (int)ceilf(x + hi + 0.01f));
+                        len = ok ? max(jhi - jlo + 1, 0) : 0;
+                    }
+                    int incl = len;
+#pragma unroll
+                    for (int s = 1; s < 64; s <<= 1) {
+                        const int v = __shfl_up(incl, s);
+                        if (lane >= s) incl += v;
+                    }
+                    if (r < hy) {
+                        rstart[r] = carry + incl - len;
+                        rlo[r] = (short)jlo;
+                    }
+                    carry += __shfl(incl, 63);
+                }
+                T = carry;
+                if (lane == 0) rstart[hy] = T;
+            }
+            wave_lds_sync();
+
+            const bool  spans = (hy <= MAXROWS);
+            const int   loops = spans ? T : ((wx > 0 && hy > 0) ? wx * hy : 0);
             const float inv_wx = 1.0f / (float)max(wx, 1);
+            int         row = 0;
 
             for (int i = lane; i < loops; i += 64) {
-                const int   row = (int)(((float)i + 0.5f) * inv_wx);
-                const int   ii = row + ymin;
-                const int   jj = i - row * wx + xmin;
+                int ii, jj;
+                if (spans) {
+                    while (i >= rstart[row + 1]) row++;
+                    jj = rlo[row] + (i - rstart[row]);
+                    ii = ymin + row;
+                } else { /* enormous patches: plain bounding-box scan */
+                    const int rr = (int)(((float)i + 0.5f) * inv_wx);
+                    ii = rr + ymin;
+                    jj = i - rr * wx + xmin;
+                }
                 const float dx = jj - x, dy = ii - y;
                 /* position in cell units relative to the keypoint: cell (ix,iy) is centred
                  * at (ix-1.5, iy-1.5); n = u - off, dn = n + off = u (s_desc_loop.cu:88-99) */
                 const float u = fmaf(crsbp, dx, srsbp * dy);
                 const float v = fmaf(crsbp, dy, -srsbp * dx);
                 if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
-                    const float* c = layer + (size_t)ii * pitch + jj;
+                    const float* c = layer + (__mul24(ii, pitch) + jj);
                     const float  gx = c[1] - c[-1];
                     const float  gy = c[pitch] - c[-pitch];
                     const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
-                    float        th = fast_atan2(gy, gx);
                     const float  ww = __expf(-0.125f * (u * u + v * v));
-
-                    th -= ang;
-                    th += (th < 0.0f ? F_PI2 : 0.0f);
-                    th -= (th >= F_PI2 ? F_PI2 : 0.0f);
-                    const float tth = th * M_4RPI;
+                    /* gradient angle relative to the keypoint orientation, in units of one bin:
+                     * rotate the gradient by -ang, then atan2 (same as atan2(gy,gx) - ang wrapped) */
+                    float tth = atan2_bins(fmaf(cos_t, gy, -sin_t * gx), fmaf(cos_t, gx, sin_t * gy));
+                    tth += (tth < 0.0f) ? 8.0f : 0.0f;
                     const float ffo = floorf(tth);
                     const float do0 = tth - ffo;
-                    const int   fo0 = (int)ffo;
-                    const int   b0 = fo0 & 7;
+                    const int   b0 = (int)ffo & 7;
 
                     /* cell centres sit at integer tu, tv in 0..3; the sample feeds cells
                      * (cx0, cx0+1) x (cy0, cy0+1) with weights (1-fx, fx) x (1-fy, fy)
@@ -437,7 +525,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
                     const float fcx = floorf(tu), fcy = floorf(tv);
                     const float fx = tu - fcx, fy = tv - fcy;
                     const int   cx0 = (int)fcx, cy0 = (int)fcy;
-                    const float wm = ww * mod;
+                    const float wm = ww * mod * fscale;
                     const float wx0 = (cx0 >= 0) ? 1.0f - fx : 0.0f;
                     const float wx1 = (cx0 <= 2) ? fx : 0.0f;
                     const float wy0 = (cy0 >= 0) ? (1.0f - fy) * wm : 0.0f;
@@ -447,7 +535,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
                     const float w1 = do0, w0 = 1.0f - do0;
 #define PS_CELL(IY, IX, WGT)                                                              \
     {                                                                                     \
-        const float wgt = (WGT) * fscale;                                                 \
+        const float wgt = (WGT);                                                          \
         if (wgt > 0.0f) {                                                                 \
             const unsigned int lo = (unsigned int)(w0 * wgt + 0.5f);                      \
             const unsigned int hi = (unsigned int)(w1 * wgt + 0.5f);                      \
@@ -464,7 +552,6 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
         }
         wave_lds_sync();
 
-        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
         /* bin b of a cell = low half of word b + high half of word b-1 (mod 8), over the copies */
         fix64     a0 = 0ull, a1 = 0ull;
         const int prevw = (lane & ~7) | ((lane + 7) & 7);
@@ -475,6 +562,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
         }
         const float inv_scale = scalbnf(1.0f, -fbits);
         float       v0 = (float)a0 * inv_scale, v1 = (float)a1 * inv_scale;
+
+        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
 #pragma unroll
@@ -530,10 +619,10 @@ __global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __r
 
 }  // namespace
 
-hipError_t launch_orientation(const PyrDesc* pd, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
-                              Ext* ext, int blocks, hipStream_t s)
+hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
+                              const InitExt* iext, Ext* ext, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orientation, dim3(blocks), dim3(256), 0, s, pd, sc, ct, iext, ext);
+    hipLaunchKernelGGL(k_orientation, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, iext, ext);
     return hipGetLastError();
 }
 
@@ -547,10 +636,10 @@ hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ex
 
 int scan_chunk() { return SCAN_CHUNK; }
 
-hipError_t launch_descriptors(const PyrDesc* pd, const SiftConsts& sc, const Counters* ct, const Ext* ext,
-                              const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
+hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
+                              const Ext* ext, const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, sc, ct, ext, map, desc, desc_cap);
+    hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     return hipGetLastError();
 }
 

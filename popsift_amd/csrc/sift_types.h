@@ -19,6 +19,8 @@
 struct OctDesc {
     float*  data;         /* L Gaussian planes   */
     float*  dog;          /* L-1 DoG planes      */
+    int64_t data_off;     /* the same, as float offsets from the arena base: kernels add them to the */
+    int64_t dog_off;      /* arena kernel argument so that plane reads are global_load, not flat_load */
     int64_t plane_stride; /* floats per plane = pitch * h */
     int     w, h, pitch;
     int     tile_begin;   /* first wave-sized work unit of this octave in the detection launch */

@@ -139,24 +139,35 @@ def main():
             "pipeline_alg_GBps": round(b_alg / (ms_dev * 1e-3) / 1e9, 1),
             "pipeline_frac_of_8TBps": round(b_alg / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         }
-        # ---- roofline of the dominant (HBM-bound) kernel: k_blur_tile ---------------------
+        # ---- roofline of the dominant (HBM-bound) kernel --------------------------------
+        # k_blur_tile<HALO,0,64>: the fused "Gaussian level + DoG" launches of the large octaves
+        # (5 per such octave; 12 algorithmic bytes per pixel: read plane l-1, write plane l + DoG l-1).
+        # Timed with HIP events on the context's own stream (C-ABI profile mode).
         c0.set_profile(True)
-        tot_ms, tot_bytes, launches = 0.0, 0.0, 0
+        big_ms = big_bytes = all_ms = all_bytes = 0.0
+        big_n = all_n = 0
         for _ in range(5):
             c0.submit_dev(ptrs[0], W, H, W)
             c0.wait()
             r = c0.report()
-            tot_ms += r.ms_blur
-            tot_bytes += r.blur_alg_bytes
-            launches += r.blur_launches
+            big_ms += r.ms_big
+            big_bytes += r.big_alg_bytes
+            big_n += r.big_launches
+            all_ms += r.ms_blur
+            all_bytes += r.blur_alg_bytes
+            all_n += r.blur_launches
         c0.set_profile(False)
-        achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        if big_n == 0:
+            big_ms, big_bytes, big_n = all_ms, all_bytes, all_n
+        achieved = big_bytes / (big_ms * 1e-3) / 1e9 if big_ms > 0 else 0.0
         roofline = {
-            "kernel": "k_blur_tile (fused H+V Gaussian level + DoG)", "bound": "hbm",
+            "kernel": "k_blur_tile<HALO,0,64> (fused H+V Gaussian level + DoG, large octaves)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "launches": launches, "avg_launch_us": round(tot_ms * 1e3 / max(launches, 1), 2),
-            "alg_bytes_per_launch": round(tot_bytes / max(launches, 1), 1),
+            "launches": big_n, "avg_launch_us": round(big_ms * 1e3 / max(big_n, 1), 2),
+            "alg_bytes_per_launch": round(big_bytes / max(big_n, 1), 1),
+            "all_blur_launches": {"launches": all_n, "avg_launch_us": round(all_ms * 1e3 / max(all_n, 1), 2),
+                                  "achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1) if all_ms > 0 else 0.0},
         }
         # ---- PCIe-inclusive end-to-end rate (host image in, host features out) -----------
         t1 = time.perf_counter()

@@ -101,6 +101,11 @@ typedef struct popsift_hip_report {
     int32_t blur_launches;  /* number of blur-level launches (profile mode)      */
     double  blur_alg_bytes; /* algorithmic bytes of those launches               */
     double  pyramid_pixels; /* sum over octaves of w*h                           */
+    /* the same three for the 64-row-tile instantiation only (k_blur_tile<HALO,0,64>:
+     * the level launches of the large octaves, the dominant kernel of the pipeline) */
+    double  big_alg_bytes;
+    float   ms_big;
+    int32_t big_launches;
 } popsift_hip_report;
 
 typedef struct popsift_hip_ctx popsift_hip_ctx;

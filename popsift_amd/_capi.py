@@ -45,6 +45,7 @@ class Report(C.Structure):
         ("ext_total", C.c_int32), ("ori_total", C.c_int32),
         ("ms_device", C.c_float), ("ms_blur", C.c_float), ("blur_launches", C.c_int32),
         ("blur_alg_bytes", C.c_double), ("pyramid_pixels", C.c_double),
+        ("big_alg_bytes", C.c_double), ("ms_big", C.c_float), ("big_launches", C.c_int32),
     ]
 
 

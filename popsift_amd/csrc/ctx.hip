@@ -41,6 +41,7 @@ struct HostTables {
 struct EventPair {
     hipEvent_t a, b;
     double     bytes;
+    bool       big; /* level launch (MODE 0) with 64-row tiles */
 };
 
 }  // namespace
@@ -297,6 +298,7 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int t
         }
         EventPair& ep = c->blur_events[c->blur_events_used++];
         ep.bytes = alg_bytes;
+        ep.big = (mode == 0 && tile_h == 64);
         HIP_TRY(c, hipEventRecord(ep.a, c->stream));
         HIP_TRY(c, launch_blur(a, mode, span, tile_h, c->stream));
         HIP_TRY(c, hipEventRecord(ep.b, c->stream));
@@ -460,12 +462,20 @@ int finish(popsift_hip_ctx* c)
     r.ms_blur = 0.0f;
     r.blur_launches = 0;
     r.blur_alg_bytes = 0.0;
+    r.ms_big = 0.0f;
+    r.big_launches = 0;
+    r.big_alg_bytes = 0.0;
     for (size_t i = 0; i < c->blur_events_used; i++) {
         float t = 0.0f;
         if (hipEventElapsedTime(&t, c->blur_events[i].a, c->blur_events[i].b) == hipSuccess) {
             r.ms_blur += t;
             r.blur_launches++;
             r.blur_alg_bytes += c->blur_events[i].bytes;
+            if (c->blur_events[i].big) {
+                r.ms_big += t;
+                r.big_launches++;
+                r.big_alg_bytes += c->blur_events[i].bytes;
+            }
         }
     }
     c->finished = true;

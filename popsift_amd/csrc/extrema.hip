@@ -354,22 +354,26 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             R.mn[z] = fminf(sn_[z], c);
         }
     };
-    float raw_next[NP];
+    /* Rolling prefetch, four rows deep: the loads of row y+4 are issued before row y+1 is
+     * consumed, so a wave keeps 4 * NP row loads in flight (the march down the strip is otherwise
+     * one memory latency per row). */
+    float q0[NP], q1[NP], q2[NP], q3[NP];
     {
         float tv[NP], ts[NP], tn[NP], ra[NP], rb[NP];
         fetch_row(yb - 1, ra);
         fetch_row(yb, rb);
-        fetch_row(yb + 1, raw_next);
+        fetch_row(min(yb + 1, ye + 1), q0);
+        fetch_row(min(yb + 2, ye + 1), q1);
+        fetch_row(min(yb + 3, ye + 1), q2);
+        fetch_row(min(yb + 4, ye + 1), q3);
         reduce_row(ra, A, tv, ts, tn);
         reduce_row(rb, B, vB, smx, smn);
     }
-    for (int y = yb; y <= ye; y++) {
-        float vC[NP], cmx[NP], cmn[NP], raw_cur[NP];
-#pragma unroll
-        for (int z = 0; z < NP; z++) raw_cur[z] = raw_next[z];
-        /* software pipeline: row y+2 is requested before row y+1 is consumed */
-        if (y + 2 <= ye + 1) fetch_row(y + 2, raw_next);
-        reduce_row(raw_cur, C, vC, cmx, cmn);
+    auto step = [&](int y, float* q) {
+        /* q holds row y+1; afterwards it is refilled with row y+5 */
+        float vC[NP], cmx[NP], cmn[NP];
+        reduce_row(q, C, vC, cmx, cmn);
+        fetch_row(min(y + 5, ye + 1), q);
         bool row_ok = lane_ok;
         if (MODE == POPSIFT_HIP_SIFT_OPENCV) row_ok = row_ok && (y >= 5 && y < h - 5);
         /* full 3x3 extremes of every plane (centre column included) */
@@ -403,6 +407,12 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             smx[z] = cmx[z];
             smn[z] = cmn[z];
         }
+    };
+    for (int y = yb; y <= ye; y += 4) {
+        step(y, q0);
+        if (y + 1 <= ye) step(y + 1, q1);
+        if (y + 2 <= ye) step(y + 2, q2);
+        if (y + 3 <= ye) step(y + 3, q3);
     }
     flush(n_buf);
 }

@@ -90,6 +90,34 @@ __device__ __forceinline__ void get_gradiant(float& grad, float& theta, int x, i
 
 /* ------------------------------------------------------------ orientation */
 
+/* atan2 for the HARD 36-bin orientation histogram (s_orientation.cu:129): needs libm-grade
+ * accuracy, because an error of e rad moves a sample across a bin edge with probability
+ * e / 0.1745.  Cephes atanf scheme (|error| ~ 1.5e-7 rad, about 1 ulp at pi/2 -- the level at
+ * which device and host libm already disagree) with Newton-refined v_rcp quotients instead of
+ * the ~12-instruction IEEE division sequence of the library routine. */
+__device__ __forceinline__ float div_nr(float a, float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+__device__ __forceinline__ float atan2_acc(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float       a = (mx == 0.0f) ? 0.0f : div_nr(mn, mx);
+    const bool  big = a > 0.4142135623730950f; /* tan(pi/8) */
+    const float t = big ? div_nr(a - 1.0f, a + 1.0f) : a;
+    const float z = t * t;
+    const float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z,
+                         -3.33329491539e-1f);
+    float       r = fmaf(p * z, t, t);
+    r = big ? r + 0.7853981633974483f : r;
+    r = (ay > ax) ? 1.5707963267948966f - r : r;
+    r = (x < 0.0f) ? 3.14159265358979323846f - r : r;
+    return (y < 0.0f) ? -r : r;
+}
+
 __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__ pdp,
                                                      const float* __restrict__ arena, SiftConsts sc,
                                                      const Counters* __restrict__ ct,
@@ -139,13 +167,15 @@ __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__
             const float  gdx = c[1] - c[-1];
             const float  gdy = c[pitch] - c[-pitch];
             const float  grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
-            const float  theta = atan2f(gdy, gdx);
+            const float  theta = atan2_acc(gdy, gdx);
             const float dx = xx - x;
             const float dy = yy - y;
             const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
             if (sq_dist <= sq_thres) {
                 const float weight = grad * __expf(sq_dist * factor);
-                int         bidx = (int)roundf((float)PS_ORI_NBINS * (theta + F_PI) / F_PI2);
+                /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the reference's quotient only when
+                 * the result is within an ulp of k + 0.5 */
+                int         bidx = (int)roundf((theta + F_PI) * ((float)PS_ORI_NBINS / F_PI2));
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
                 if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));
             }

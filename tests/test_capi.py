@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_header(hip):
     assert C.sizeof(hip.Params) == 20 * 4
     assert hip.FEATURE_DTYPE.itemsize == 52          # 5 scalars + 4 angles + 4 indices
     assert hip.EXTREMUM_DTYPE.itemsize == 24
-    assert C.sizeof(hip.Report) == (3 + 20 + 20 + 2) * 4 + 3 * 4 + 2 * 8
+    assert C.sizeof(hip.Report) == (3 + 20 + 20 + 2) * 4 + 3 * 4 + 2 * 8 + 8 + 4 + 4
 
 
 def test_default_params_are_the_reference_defaults(hip):

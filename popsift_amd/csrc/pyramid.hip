@@ -30,7 +30,6 @@ namespace popsift_hip {
 namespace {
 
 constexpr int TW = 128; /* tile width  (outputs) */
-constexpr int NT = 256; /* threads per workgroup */
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -86,7 +85,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
  *            of ds_read_b128 rows; 16 B stores of the Gaussian plane and of
  *            DoG = new - old (old re-read from L2 as one 16 B load)
  */
-template <int HALO, int MODE, int TH>
+template <int HALO, int MODE, int TH, int NT>
 __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 {
     constexpr int HP = (HALO + 3) & ~3;   /* left/right halo, padded to 16 B   */
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
         __shared__ int   s_iy[SR];
         __shared__ float s_fb[SR];
         __shared__ float s_lut[256]; /* cudaReadModeNormalizedFloat: v / 255 */
-        if (MODE == 1) s_lut[tid] = (float)tid / 255.0f;
+        if (MODE == 1 && tid < 256) s_lut[tid] = (float)tid / 255.0f;
         for (int c = tid; c < SW; c += NT) {
             const int   X = tx0 + c - HP;
             const float read_x = ((float)X + a.shift) / (float)w;
@@ -334,14 +333,14 @@ __global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src,
     dst[(size_t)y * dpitch + x] = src[(size_t)ry * spitch + rx];
 }
 
-template <int MODE, int TH>
+template <int MODE, int TH, int NT>
 hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
 {
     const dim3 grid(a.tiles_x * a.tiles_y), block(NT);
-#define PS_CASE(H)                                                             \
-    if (halo <= H) {                                                           \
-        hipLaunchKernelGGL((k_blur_tile<H, MODE, TH>), grid, block, 0, s, a);  \
-        return hipGetLastError();                                              \
+#define PS_CASE(H)                                                                 \
+    if (halo <= H) {                                                               \
+        hipLaunchKernelGGL((k_blur_tile<H, MODE, TH, NT>), grid, block, 0, s, a);  \
+        return hipGetLastError();                                                  \
     }
     PS_CASE(4)
     PS_CASE(5)
@@ -378,17 +377,30 @@ hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStr
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    if (tile_h == 64) {
+    static const int nt64 = []() {
+        const char* e = getenv("POPSIFT_HIP_BLUR_NT64"); /* tuning knob: lanes per 64-row tile */
+        return (e && atoi(e) == 256) ? 256 : 512;
+    }();
+    /* 512 lanes per 64-row tile halve the serial work per wave at the same LDS footprint (measured
+     * -12 % per launch); the 27-tap instance needs ~150 VGPRs for its vertical window and is better
+     * off with 256 lanes */
+    if (tile_h == 64 && nt64 == 512 && halo <= 10) {
         switch (mode) {
-        case 0: return launch_blur_mode<0, 64>(a, halo, s);
-        case 1: return launch_blur_mode<1, 64>(a, halo, s);
-        case 2: return launch_blur_mode<2, 64>(a, halo, s);
+        case 0: return launch_blur_mode<0, 64, 512>(a, halo, s);
+        case 1: return launch_blur_mode<1, 64, 512>(a, halo, s);
+        case 2: return launch_blur_mode<2, 64, 512>(a, halo, s);
+        }
+    } else if (tile_h == 64) {
+        switch (mode) {
+        case 0: return launch_blur_mode<0, 64, 256>(a, halo, s);
+        case 1: return launch_blur_mode<1, 64, 256>(a, halo, s);
+        case 2: return launch_blur_mode<2, 64, 256>(a, halo, s);
         }
     } else if (tile_h == 32) {
         switch (mode) {
-        case 0: return launch_blur_mode<0, 32>(a, halo, s);
-        case 1: return launch_blur_mode<1, 32>(a, halo, s);
-        case 2: return launch_blur_mode<2, 32>(a, halo, s);
+        case 0: return launch_blur_mode<0, 32, 256>(a, halo, s);
+        case 1: return launch_blur_mode<1, 32, 256>(a, halo, s);
+        case 2: return launch_blur_mode<2, 32, 256>(a, halo, s);
         }
     }
     return hipErrorInvalidValue;

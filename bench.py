@@ -39,8 +39,21 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images in flight per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-roofline", action="store_true",
+                    help="run only the single-context roofline pass (the command profiles/ *_roofline_pass* was taken with)")
     ap.add_argument("--cpu-images", type=int, default=2, help="images timed for the CPU baseline")
     return ap.parse_args()
+
+
+def blur_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this configuration
+    (FETCH_SIZE x2 + WRITE_SIZE, separate passes; tools/collect_profiles.sh -> profiles/blur_traffic.json).
+    PMC collection cannot run inside the timed process, so the committed measurement is quoted."""
+    try:
+        with open(os.path.join(HERE, "profiles", "blur_traffic.json")) as f:
+            return round(json.load(f)["traffic_bytes_per_launch"], 1)
+    except Exception:
+        return None
 
 
 def run_step(ctxs, ptrs, pool):
@@ -84,7 +97,7 @@ def main():
     from popsift_amd import _capi as hip
     from popsift_amd.synth import synth
 
-    B = args.batch
+    B = 1 if args.only_roofline else args.batch
     # config 4 seeds 100.. for batches; config 2's own image (seed 2) is image 0 of rank 0
     seeds = [2 if (rank == 0 and i == 0) else 100 + rank * B + i for i in range(B)]
     host_imgs = [synth(s, W, H) for s in seeds]
@@ -98,6 +111,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.only_roofline:
+        args.steps, args.warmup = 1, 0
     for _ in range(args.warmup):
         run_step(ctxs, ptrs, pool)
     barrier()
@@ -163,7 +178,7 @@ def main():
         roofline = {
             "kernel": "k_blur_tile<HALO,0,64> (fused H+V Gaussian level + DoG, large octaves)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": blur_traffic(),
             "launches": big_n, "avg_launch_us": round(big_ms * 1e3 / max(big_n, 1), 2),
             "alg_bytes_per_launch": round(big_bytes / max(big_n, 1), 1),
             "all_blur_launches": {"launches": all_n, "avg_launch_us": round(all_ms * 1e3 / max(all_n, 1), 2),
@@ -171,14 +186,15 @@ def main():
         }
         # ---- PCIe-inclusive end-to-end rate (host image in, host features out) -----------
         t1 = time.perf_counter()
-        n_e2e = 8
+        n_e2e = 0 if args.only_roofline else 8
         for k in range(n_e2e):
             c0.submit(host_imgs[0])
             c0.fetch()
-        extra["host_to_host_single_ctx_mpix_s"] = round(n_e2e * W * H / 1e6 / (time.perf_counter() - t1), 1)
+        if n_e2e:
+            extra["host_to_host_single_ctx_mpix_s"] = round(n_e2e * W * H / 1e6 / (time.perf_counter() - t1), 1)
 
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.only_roofline:
             from oracle import oracle as O  # checker / reported baseline only
             # a 1-GPU box grants a 16-core CPU share; more OpenMP threads than that only oversubscribe
             cores = min(os.cpu_count() or 1, 16)

@@ -89,10 +89,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the extraction path has no CPU fallback)")
+    # Rehearsal knobs (1-GPU box only): BENCH_FORCE_DEVICE=0 puts every rank on one card and
+    # BENCH_BACKEND=gloo swaps RCCL for gloo, to exercise the N>1 control path without N GPUs.
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from popsift_amd import _capi as hip
     from popsift_amd.synth import synth
@@ -125,8 +133,9 @@ def main():
 
     feats = sum(c.report().ext_total for c in ctxs)
     descs = sum(c.report().ori_total for c in ctxs)
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([feats, descs], dtype=torch.float64, device="cuda")
+    rdev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    cnt = torch.tensor([feats, descs], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)

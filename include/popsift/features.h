@@ -64,8 +64,8 @@ public:
 
     /* (re)allocates page-aligned arrays for num_ext features / num_ori descriptors */
     void reset(int num_ext, int num_ori);
-    /* host-memory registration with the GPU runtime; no-ops here (results are staged
-     * through the context's own pinned buffers) but kept for source compatibility */
+    /* host-memory registration with the GPU runtime; no-ops here (the arrays already are
+     * pinned blocks from a process-wide pool) but kept for source compatibility */
     void pin() {}
     void unpin() {}
 

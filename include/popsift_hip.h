@@ -156,6 +156,12 @@ int popsift_hip_fetch(popsift_hip_ctx* ctx, popsift_hip_feature* feats, size_t f
  * stay valid until the next submit on this context. */
 int popsift_hip_results_dev(popsift_hip_ctx* ctx, const void** d_feats, const void** d_desc);
 
+/* Pinned (page-locked) host memory for result buffers: a D2H copy into it runs at PCIe speed
+ * without staging.  Replaces FeaturesHost::pin/unpin (cudaHostRegister per image,
+ * features.cu:84-109).  Returns NULL on failure / when no GPU runtime is usable. */
+void* popsift_hip_host_alloc(size_t bytes);
+void  popsift_hip_host_free(void* p);
+
 int popsift_hip_get_report(const popsift_hip_ctx* ctx, popsift_hip_report* rep);
 /* profile != 0: bracket every blur-level launch with HIP events (serialises the
  * octave streams; used by bench.py for the roofline object only). */

@@ -77,6 +77,8 @@ SYMBOLS = [
     ("popsift_hip_wait", C.c_int, [_vp, _ip, _ip]),
     ("popsift_hip_fetch", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("popsift_hip_results_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("popsift_hip_host_alloc", _vp, [C.c_size_t]),
+    ("popsift_hip_host_free", None, [_vp]),
     ("popsift_hip_get_report", C.c_int, [_vp, C.POINTER(Report)]),
     ("popsift_hip_set_profile", C.c_int, [_vp, C.c_int]),
     ("popsift_hip_octave_dims", C.c_int, [_vp, C.c_int, _ip, _ip]),

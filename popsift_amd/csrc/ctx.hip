@@ -690,6 +690,19 @@ int popsift_hip_results_dev(popsift_hip_ctx* c, const void** d_feats, const void
     return POPSIFT_HIP_OK;
 }
 
+void* popsift_hip_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+
+void popsift_hip_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int popsift_hip_get_report(const popsift_hip_ctx* c, popsift_hip_report* rep)
 {
     if (!c || !rep) return POPSIFT_HIP_ERR_INVALID;

@@ -83,7 +83,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
  *            which read their 9 x ds_read_b128 windows before the ds_write_b128
  *   phase 3  vertical pass, 4 columns x 4 rows per lane from a register window
  *            of ds_read_b128 rows; 16 B stores of the Gaussian plane and of
- *            DoG = new - old (old re-read from L2 as one 16 B load)
+ *            DoG = new - old (old kept in registers since phase 2: the same lane
+ *            owns the same 4x4 block in both passes)
  */
 template <int HALO, int MODE, int TH, int NT>
 __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
@@ -250,50 +251,61 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
     __syncthreads();
 
     /* ---- phase 2: horizontal pass in place, 4 outputs per lane ----------- */
-    {
-        const int lx = (tid & 31) * 4; /* first output column of this lane */
-        for (int r = tid >> 5; r < SR; r += NT / 32) {
-            v4f        win[NW];
-            const v4f* p = reinterpret_cast<const v4f*>(&s_t[r * SW + lx]);
+    /* Lane (rg, cx) = (tid / 32, 4 * (tid % 32)) owns the 4x4 output block rows 4rg..4rg+3, columns
+     * cx..cx+3 in BOTH passes: while it filters its four centre rows it keeps their source values
+     * (the old plane, needed for the DoG) in registers, so the vertical pass does not read the old
+     * plane again.  The 2*HALO halo rows are filtered afterwards, spread over the half-waves. */
+    constexpr int GROUPS = (TH / 4) / (NT / 32); /* 4-row groups per lane */
+    const int     lx = (tid & 31) * 4;           /* first output column of this lane */
+    v4f           old[GROUPS][4];
+    auto hrow = [&](int r) -> v4f {
+        v4f        win[NW];
+        const v4f* p = reinterpret_cast<const v4f*>(&s_t[r * SW + lx]);
 #pragma unroll
-            for (int j = 0; j < NW; j++) win[j] = p[j];
+        for (int j = 0; j < NW; j++) win[j] = p[j];
 #define PS_W(i) win[(i) >> 2][(i) & 3]
-            v4f out;
+        v4f out;
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int cpos = HP + o; /* centre of output o inside the window */
-                float     acc;
-                if (MODE == 0) {
-                    acc = PS_W(cpos) * a.taps.g[0];
+        for (int o = 0; o < 4; o++) {
+            const int cpos = HP + o; /* centre of output o inside the window */
+            float     acc;
+            if (MODE == 0) {
+                acc = PS_W(cpos) * a.taps.g[0];
 #pragma unroll
-                    for (int k = HALO; k > 0; k--)
-                        acc = fmaf(PS_W(cpos - k) + PS_W(cpos + k), a.taps.g[k], acc);
-                } else {
-                    acc = 0.0f;
+                for (int k = HALO; k > 0; k--) acc = fmaf(PS_W(cpos - k) + PS_W(cpos + k), a.taps.g[k], acc);
+            } else {
+                acc = 0.0f;
 #pragma unroll
-                    for (int k = HALO; k > 0; k--)
-                        acc = fmaf(PS_W(cpos - k) + PS_W(cpos + k), a.taps.g[k], acc);
-                    acc = fmaf(PS_W(cpos), a.taps.g[0], acc);
-                    acc = acc * 255.0f;
-                }
-                out[o] = acc;
+                for (int k = HALO; k > 0; k--) acc = fmaf(PS_W(cpos - k) + PS_W(cpos + k), a.taps.g[k], acc);
+                acc = fmaf(PS_W(cpos), a.taps.g[0], acc);
+                acc = acc * 255.0f;
             }
-#undef PS_W
-            /* every lane of this row has issued its reads above (same wave, in order) */
-            *reinterpret_cast<v4f*>(&s_t[r * SW + HP + lx]) = out;
+            out[o] = acc;
         }
+#undef PS_W
+        /* every lane of this row has issued its reads above (same wave, in order) */
+        *reinterpret_cast<v4f*>(&s_t[r * SW + HP + lx]) = out;
+        return win[HP / 4]; /* the four source values under this lane's outputs */
+    };
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++) {
+        const int rg = (tid >> 5) + g * (NT / 32);
+#pragma unroll
+        for (int j = 0; j < 4; j++) old[g][j] = hrow(HALO + 4 * rg + j);
     }
+    for (int hh = tid >> 5; hh < 2 * HALO; hh += NT / 32) (void)hrow(hh < HALO ? hh : TH + hh);
     __syncthreads();
 
     /* ---- phase 3: vertical pass, 4 columns x 4 rows per lane, + DoG ------ */
     {
-        const int cx = (tid & 31) * 4;
-        const int gx = tx0 + cx;
-        for (int rg = tid >> 5; rg < TH / 4; rg += NT / 32) {
+        const int gx = tx0 + lx;
+#pragma unroll
+        for (int g = 0; g < GROUPS; g++) {
+            const int rg = (tid >> 5) + g * (NT / 32);
             const int r0 = rg * 4; /* first output row (tile-relative) */
             v4f       win[VW];
 #pragma unroll
-            for (int j = 0; j < VW; j++) win[j] = *reinterpret_cast<const v4f*>(&s_t[(r0 + j) * SW + HP + cx]);
+            for (int j = 0; j < VW; j++) win[j] = *reinterpret_cast<const v4f*>(&s_t[(r0 + j) * SW + HP + lx]);
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int cpos = HALO + o;
@@ -311,10 +323,7 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                 if (gx < w && gy < h) {
                     /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
-                    if (MODE == 0) {
-                        const v4f old = *reinterpret_cast<const v4f*>(&a.src[(size_t)gy * pitch + gx]);
-                        *reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]) = acc - old;
-                    }
+                    if (MODE == 0) *reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]) = acc - old[g][o];
                 }
             }
         }

@@ -83,6 +83,8 @@ struct popsift_hip_ctx {
     int2*     d_cand = nullptr;
     int       cand_cap = 0;
     int*      d_partial = nullptr; /* one partial sum per scan chunk */
+    int*      d_ovf = nullptr;     /* detection strips handed to the slow pass */
+    size_t    ovf_cap = 0;
     size_t    partial_cap = 0;
 
     /* profiling */
@@ -169,6 +171,10 @@ void init_tables(popsift_hip_ctx* c)
     sc.sift_mode = p.sift_mode;
     sc.grid_size = p.filter_grid_size > 0 ? p.filter_grid_size : 1;
     sc.up_fac_int = (int)p.upscale_factor;
+    {
+        const char* e = getenv("POPSIFT_HIP_DET_QCAP"); /* test hook: force strips into the slow detection pass */
+        sc.det_qcap = e ? std::max(atoi(e), 0) : (1 << 30);
+    }
 }
 
 /* PopSift::private_init, popsift.cpp:89-120 */
@@ -274,6 +280,7 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
         return rc;
     if (int rc = ensure_cand_cap(c, 1 << 20)) return rc;
+    if (int rc = grow(c, &c->d_ovf, &c->ovf_cap, (size_t)tiles + 1)) return rc;
     /* the stream is idle here (submit drains the previous image first), so h_pd is free to reuse */
     *c->h_pd = c->pd;
     HIP_TRY(c, hipMemcpyAsync(c->d_pd, c->h_pd, sizeof(PyrDesc), hipMemcpyHostToDevice, c->stream));
@@ -366,7 +373,8 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
-    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_iext, c->stream));
+    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_ovf, c->d_iext,
+                              c->stream));
     HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_iext, c->d_ext, 8192, c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->desc_cap,
@@ -625,6 +633,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->h_pd) (void)hipHostFree(c->h_pd);
     if (c->d_cand) (void)hipFree(c->d_cand);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->h_ct) (void)hipHostFree(c->h_ct);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

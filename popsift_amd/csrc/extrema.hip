@@ -279,142 +279,170 @@ struct RowRed {
     float mx[NP], mn[NP];
 };
 
-/* LEVELS = DoG search levels; NP = LEVELS + 2 DoG planes */
-template <int MODE, int LEVELS>
+/*
+ * LEVELS = DoG search levels; NP = LEVELS + 2 DoG planes.
+ *
+ * Memory pipeline.  A strip is walked in groups of DET_G rows: all DET_G * NP row loads of a group
+ * are issued together and consumed one row at a time (counted vmcnt waits), and NOTHING else
+ * touches the vector-memory queue inside a group.  An earlier version flushed the candidate queue
+ * to global memory from inside the row loop; the mere presence of that conditional store path made
+ * the compiler drain the queue (s_waitcnt vmcnt(0)) at every row, i.e. one exposed memory latency
+ * per row (73 % of the wave cycles were waits).  Now candidates only go to the wave's LDS queue in
+ * the loop and are flushed once, after the strip.  A strip with more than DET_Q candidates (never
+ * seen outside synthetic stress images; typical is ~50) is handed to the SLOW instantiation of this
+ * kernel, which re-does it with a flush per row.
+ */
+constexpr int DET_G = 8;   /* rows per load group */
+constexpr int DET_Q = 512; /* per-wave candidate queue (entries) */
+
+template <int MODE, int LEVELS, bool SLOW>
 __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
                                                 SiftConsts sc, Counters* __restrict__ ct, int2* __restrict__ cand,
-                                                int cand_cap)
+                                                int cand_cap, int* __restrict__ ovf)
 {
-    const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (unit >= pdp->total_tiles) return;
-    const int n_oct = pdp->n_oct;
-    int       o = 0;
-    while (o + 1 < n_oct && unit >= pdp->o[o + 1].tile_begin) o++;
-    const OctDesc od = pdp->o[o];
-    const int      w = od.w, h = od.h;
-    const int      strips = (w - 2 + DET_W - 1) / DET_W;
-    const int      u = unit - od.tile_begin;
-    const int      cy = u / strips, sx = u - cy * strips;
-    const int      x = sx * DET_W + lane;
-    const int      xc = min(x, w - 1);
-    const int      yb = 1 + cy * DET_RH;
-    const int      ye = min(yb + DET_RH - 1, h - 2);
-    if (strips <= 0 || yb > ye) return;
-
-    const float first_thr = (MODE == POPSIFT_HIP_SIFT_OPENCV)   ? floorf(sc.threshold)
-                            : (MODE == POPSIFT_HIP_SIFT_VLFEAT) ? 0.8f * 2.0f * sc.threshold
-                                                                : 1.6f * sc.threshold;
-    bool lane_ok = (lane >= 1 && lane <= DET_W && x <= w - 2);
-    if (MODE == POPSIFT_HIP_SIFT_OPENCV) lane_ok = lane_ok && (x >= 5 && x < w - 5);
-
-    /* Candidates are staged per wave in LDS and flushed with ONE global atomicAdd
-     * per ~DET_Q entries: a returning atomic on a single hot counter saturates
-     * at ~90 per microsecond (MI355X_MICROARCH.md "dequeue"), which made a
-     * per-row atomic the whole cost of this kernel. */
-    constexpr int   DET_Q = (128 * LEVELS > 512) ? 128 * LEVELS : 512; /* >= 2 rows' worth of hits */
-    __shared__ int2 s_queue[4][DET_Q];
+    constexpr int   NP = LEVELS + 2;
+    constexpr int   QCAP = SLOW ? ((128 * LEVELS > DET_Q) ? 128 * LEVELS : DET_Q) : DET_Q;
+    __shared__ int2 s_queue[4][QCAP];
+    const int       lane = threadIdx.x & 63;
     int2*           queue = s_queue[threadIdx.x >> 6];
-    int             n_buf = 0;
-    auto            flush = [&](int n) -> int {
-        if (n == 0) return 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int basei = 0;
-        if (lane == 0) basei = atomicAdd(&ct->pad[0], n);
-        basei = __shfl(basei, 0);
-        for (int i = lane; i < n; i += 64)
-            if (basei + i < cand_cap) cand[basei + i] = queue[i];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        return 0;
-    };
+    const int       n_oct = pdp->n_oct;
+    const int       n_units = SLOW ? min(ct->pad[1], pdp->total_tiles) : pdp->total_tiles;
+    const float     first_thr = (MODE == POPSIFT_HIP_SIFT_OPENCV)   ? floorf(sc.threshold)
+                                : (MODE == POPSIFT_HIP_SIFT_VLFEAT) ? 0.8f * 2.0f * sc.threshold
+                                                                    : 1.6f * sc.threshold;
 
-    constexpr int NP = LEVELS + 2;
-    const float*  base = arena + od.dog_off + xc;
-    RowRed<NP>    A, B, C;
-    float         vB[NP], smx[NP], smn[NP];
+    for (int ui = blockIdx.x * 4 + (threadIdx.x >> 6); ui < n_units; ui += gridDim.x * 4) {
+        const int unit = SLOW ? ovf[ui] : ui;
+        int       o = 0;
+        while (o + 1 < n_oct && unit >= pdp->o[o + 1].tile_begin) o++;
+        const OctDesc od = pdp->o[o];
+        const int     w = od.w, h = od.h;
+        const int     strips = (w - 2 + DET_W - 1) / DET_W;
+        const int     u = unit - od.tile_begin;
+        const int     cy = u / strips, sx = u - cy * strips;
+        const int     x = sx * DET_W + lane;
+        const int     xc = min(x, w - 1);
+        const int     yb = 1 + cy * DET_RH;
+        const int     ye = min(yb + DET_RH - 1, h - 2);
+        if (strips <= 0 || yb > ye) continue;
 
-    /* raw loads of one row of all NP planes (issued early, consumed one iteration later) */
-    auto fetch_row = [&](int y, float* raw) {
-        const float* p = base + (int64_t)y * od.pitch;
+        bool lane_ok = (lane >= 1 && lane <= DET_W && x <= w - 2);
+        if (MODE == POPSIFT_HIP_SIFT_OPENCV) lane_ok = lane_ok && (x >= 5 && x < w - 5);
+
+        int       n_buf = 0;
+        bool      overflow = false;
+        const int qcap = SLOW ? QCAP : min(sc.det_qcap, QCAP);
+        auto flush = [&](int n) -> int {
+            if (n == 0) return 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int basei = 0;
+            if (lane == 0) basei = atomicAdd(&ct->pad[0], n);
+            basei = __shfl(basei, 0);
+            for (int i = lane; i < n; i += 64)
+                if (basei + i < cand_cap) cand[basei + i] = queue[i];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            return 0;
+        };
+
+        const float* base = arena + od.dog_off + xc;
+        RowRed<NP>   A, B, C;
+        float        vB[NP], smx[NP], smn[NP];
+
+        auto fetch_row = [&](int y, float* raw) {
+            const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
-        for (int z = 0; z < NP; z++) raw[z] = p[z * od.plane_stride];
-    };
-    auto reduce_row = [&](const float* raw, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
+            for (int z = 0; z < NP; z++) raw[z] = p[z * od.plane_stride];
+        };
+        auto reduce_row = [&](const float* raw, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
 #pragma unroll
-        for (int z = 0; z < NP; z++) {
-            const float c = raw[z];
-            const float l = lane_left(c);
-            const float r = lane_right(c);
-            v[z] = c;
-            sx_[z] = fmaxf(l, r);
-            sn_[z] = fminf(l, r);
-            R.mx[z] = fmaxf(sx_[z], c);
-            R.mn[z] = fminf(sn_[z], c);
+            for (int z = 0; z < NP; z++) {
+                const float c = raw[z];
+                const float l = lane_left(c);
+                const float r = lane_right(c);
+                v[z] = c;
+                sx_[z] = fmaxf(l, r);
+                sn_[z] = fminf(l, r);
+                R.mx[z] = fmaxf(sx_[z], c);
+                R.mn[z] = fminf(sn_[z], c);
+            }
+        };
+        {
+            float tv[NP], ts[NP], tn[NP], ra[NP], rb[NP];
+            fetch_row(yb - 1, ra);
+            fetch_row(yb, rb);
+            reduce_row(ra, A, tv, ts, tn);
+            reduce_row(rb, B, vB, smx, smn);
         }
-    };
-    /* Rolling prefetch, four rows deep: the loads of row y+4 are issued before row y+1 is
-     * consumed, so a wave keeps 4 * NP row loads in flight (the march down the strip is otherwise
-     * one memory latency per row). */
-    float q0[NP], q1[NP], q2[NP], q3[NP];
-    {
-        float tv[NP], ts[NP], tn[NP], ra[NP], rb[NP];
-        fetch_row(yb - 1, ra);
-        fetch_row(yb, rb);
-        fetch_row(min(yb + 1, ye + 1), q0);
-        fetch_row(min(yb + 2, ye + 1), q1);
-        fetch_row(min(yb + 3, ye + 1), q2);
-        fetch_row(min(yb + 4, ye + 1), q3);
-        reduce_row(ra, A, tv, ts, tn);
-        reduce_row(rb, B, vB, smx, smn);
-    }
-    auto step = [&](int y, float* q) {
-        /* q holds row y+1; afterwards it is refilled with row y+5 */
-        float vC[NP], cmx[NP], cmn[NP];
-        reduce_row(q, C, vC, cmx, cmn);
-        fetch_row(min(y + 5, ye + 1), q);
-        bool row_ok = lane_ok;
-        if (MODE == POPSIFT_HIP_SIFT_OPENCV) row_ok = row_ok && (y >= 5 && y < h - 5);
-        /* full 3x3 extremes of every plane (centre column included) */
-        float fmx[NP], fmn[NP];
+        /* one row: q holds row y+1 */
+        auto step = [&](int y, const float* q) {
+            float vC[NP], cmx[NP], cmn[NP];
+            reduce_row(q, C, vC, cmx, cmn);
+            bool row_ok = lane_ok && (y <= ye);
+            if (MODE == POPSIFT_HIP_SIFT_OPENCV) row_ok = row_ok && (y >= 5 && y < h - 5);
+            /* full 3x3 extremes of every plane (centre column included) */
+            float fmx[NP], fmn[NP];
 #pragma unroll
-        for (int z = 0; z < NP; z++) {
-            fmx[z] = fmaxf(fmaxf(A.mx[z], B.mx[z]), C.mx[z]);
-            fmn[z] = fminf(fminf(A.mn[z], B.mn[z]), C.mn[z]);
-        }
+            for (int z = 0; z < NP; z++) {
+                fmx[z] = fmaxf(fmaxf(A.mx[z], B.mx[z]), C.mx[z]);
+                fmn[z] = fminf(fminf(A.mn[z], B.mn[z]), C.mn[z]);
+            }
 #pragma unroll
-        for (int z = 1; z <= LEVELS; z++) {
-            const float v = vB[z];
-            const float omx = fmaxf(fmaxf(A.mx[z], smx[z]), C.mx[z]); /* own plane, centre excluded */
-            const float omn = fminf(fminf(A.mn[z], smn[z]), C.mn[z]);
-            const float nmax = fmaxf(fmaxf(fmx[z - 1], fmx[z + 1]), omx);
-            const float nmin = fminf(fminf(fmn[z - 1], fmn[z + 1]), omn);
-            const bool  hit = row_ok && (fabsf(v) >= first_thr) && (v > nmax || v < nmin);
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                /* stage in the wave's LDS queue; n_buf is wave-uniform */
-                if (hit) queue[n_buf + __popcll(mask & ((1ull << lane) - 1ull))] = make_int2(x | (y << 16), z | (o << 8));
-                n_buf += __popcll(mask);
+            for (int z = 1; z <= LEVELS; z++) {
+                const float v = vB[z];
+                const float omx = fmaxf(fmaxf(A.mx[z], smx[z]), C.mx[z]); /* own plane, centre excluded */
+                const float omn = fminf(fminf(A.mn[z], smn[z]), C.mn[z]);
+                const float nmax = fmaxf(fmaxf(fmx[z - 1], fmx[z + 1]), omx);
+                const float nmin = fminf(fminf(fmn[z - 1], fmn[z + 1]), omn);
+                const bool  hit = row_ok && (fabsf(v) >= first_thr) && (v > nmax || v < nmin);
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    /* stage in the wave's LDS queue; n_buf is wave-uniform */
+                    const int cnt = __popcll(mask);
+                    if (n_buf + cnt <= qcap) {
+                        if (hit)
+                            queue[n_buf + __popcll(mask & ((1ull << lane) - 1ull))] =
+                                make_int2(x | (y << 16), z | (o << 8));
+                        n_buf += cnt;
+                    } else {
+                        overflow = true;
+                    }
+                }
+            }
+            A = B;
+            B = C;
+#pragma unroll
+            for (int z = 0; z < NP; z++) {
+                vB[z] = vC[z];
+                smx[z] = cmx[z];
+                smn[z] = cmn[z];
+            }
+        };
+        if (SLOW) {
+            for (int y = yb; y <= ye; y++) {
+                float q[NP];
+                fetch_row(y + 1, q);
+                step(y, q);
+                if (n_buf > QCAP - 64 * LEVELS) n_buf = flush(n_buf);
+            }
+            flush(n_buf);
+        } else {
+            for (int y0 = yb; y0 <= ye; y0 += DET_G) {
+                float q[DET_G][NP];
+#pragma unroll
+                for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + k + 1, ye + 1), q[k]);
+#pragma unroll
+                for (int k = 0; k < DET_G; k++) step(y0 + k, q[k]);
+            }
+            if (overflow) {
+                /* too many candidates for the queue: leave the whole strip to the SLOW pass */
+                if (lane == 0) ovf[atomicAdd(&ct->pad[1], 1)] = unit;
+            } else {
+                flush(n_buf);
             }
         }
-        if (n_buf > DET_Q - 64 * LEVELS) n_buf = flush(n_buf);
-        A = B;
-        B = C;
-#pragma unroll
-        for (int z = 0; z < NP; z++) {
-            vB[z] = vC[z];
-            smx[z] = cmx[z];
-            smn[z] = cmn[z];
-        }
-    };
-    for (int y = yb; y <= ye; y += 4) {
-        step(y, q0);
-        if (y + 1 <= ye) step(y + 1, q1);
-        if (y + 2 <= ye) step(y + 2, q2);
-        if (y + 3 <= ye) step(y + 3, q3);
     }
-    flush(n_buf);
 }
 
 /* Refinement of the compacted candidates: one lane per candidate, dense waves. */
@@ -476,13 +504,14 @@ int extrema_units(int w, int h)
 
 template <int MODE>
 static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
-                          Counters* ct, int2* cand, int cand_cap, hipStream_t s)
+                          Counters* ct, int2* cand, int cand_cap, int* ovf, hipStream_t s)
 {
-    const dim3 grid((pd.total_tiles + 3) / 4), block(256);
+    const dim3 grid((pd.total_tiles + 3) / 4), block(256), sgrid(64);
     switch (pd.levels) {
-#define PS_LV(N)                                                                                   \
-    case N:                                                                                        \
-        hipLaunchKernelGGL((k_detect<MODE, N>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap); \
+#define PS_LV(N)                                                                                              \
+    case N:                                                                                                   \
+        hipLaunchKernelGGL((k_detect<MODE, N, false>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+        hipLaunchKernelGGL((k_detect<MODE, N, true>), sgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
         break;
         PS_LV(2) PS_LV(3) PS_LV(4) PS_LV(5) PS_LV(6) PS_LV(7) PS_LV(8) PS_LV(9)
 #undef PS_LV
@@ -490,22 +519,22 @@ static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
 }
 
 hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
-                          Counters* ct, int2* cand, int cand_cap, InitExt* iext, hipStream_t s)
+                          Counters* ct, int2* cand, int cand_cap, int* ovf, InitExt* iext, hipStream_t s)
 {
     if (pd.total_tiles <= 0) return hipSuccess;
     if (pd.levels < 2 || pd.levels > 9) return hipErrorInvalidValue;
     const dim3 block(256), rgrid(1024);
     switch (sc.sift_mode) {
     case POPSIFT_HIP_SIFT_OPENCV:
-        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, arena, sc, ct, cand, cand_cap, s);
+        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
         hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     case POPSIFT_HIP_SIFT_VLFEAT:
-        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, arena, sc, ct, cand, cand_cap, s);
+        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
         hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     default:
-        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, arena, sc, ct, cand, cand_cap, s);
+        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
         hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     }

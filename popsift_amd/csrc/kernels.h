@@ -31,7 +31,7 @@ hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* 
 /* extrema.hip */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */
 hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, int2* cand,
-                          int cand_cap, InitExt* iext, hipStream_t s);
+                          int cand_cap, int* ovf, InitExt* iext, hipStream_t s);
 
 /* keypoint.hip */
 hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, const Counters* ct, const InitExt* iext,

@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
                     const float  gx = c[1] - c[-1];
                     const float  gy = c[pitch] - c[-pitch];
                     const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
-                    const float  ww = __expf(-0.125f * (u * u + v * v));
+                    /* exp(-(u^2+v^2)/8) = 2^(-(u^2+v^2) * log2(e)/8) */
+                    const float  ww = __builtin_amdgcn_exp2f(-0.18033688011112042f * (u * u + v * v));
                     /* gradient angle relative to the keypoint orientation, in units of one bin:
                      * rotate the gradient by -ang, then atan2 (same as atan2(gy,gx) - ang wrapped) */
                     float tth = atan2_bins(fmaf(cos_t, gy, -sin_t * gx), fmaf(cos_t, gx, sin_t * gy));
@@ -567,8 +568,8 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
     {                                                                                     \
         const float wgt = (WGT);                                                          \
         if (wgt > 0.0f) {                                                                 \
-            const unsigned int lo = (unsigned int)(w0 * wgt + 0.5f);                      \
-            const unsigned int hi = (unsigned int)(w1 * wgt + 0.5f);                      \
+            const unsigned int lo = (unsigned int)fmaf(w0, wgt, 0.5f);                    \
+            const unsigned int hi = (unsigned int)fmaf(w1, wgt, 0.5f);                    \
             atomicAdd(&hist[((((IY) << 2) + (IX)) << 3) + b0], ((fix64)hi << 32) | lo);  \
         }                                                                                 \
     }

@@ -40,6 +40,7 @@ struct SiftConsts {
     int   max_extrema, norm_multi, norm_mode, sift_mode;
     int   grid_size;
     int   up_fac_int; /* prep_features(Descriptor*, int up_fac): truncated, sift_pyramid.cu:250 */
+    int   det_qcap;   /* candidate queue entries the fast detection pass may use (tests shrink it) */
 };
 
 /* sift_extremum.h:24-33 InitialExtremum (without the grid-filter bookkeeping) */
@@ -69,5 +70,5 @@ struct Counters {
     int ori_ps[PS_MAX_OCT];
     int ext_total;
     int ori_total;
-    int pad[2];
+    int pad[2]; /* [0] candidates found by the detection kernel, [1] strips left to its slow pass */
 };

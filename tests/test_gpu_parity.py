@@ -233,3 +233,18 @@ def test_call_sequence_errors(gpu_hip):
     assert rc in (gpu_hip.ERR_TOO_SMALL, gpu_hip.ERR_INVALID)
     rc = gpu_hip.lib().popsift_hip_submit_u8(ctx._h, img.ctypes.data, 64, 48, 10)
     assert rc == gpu_hip.ERR_INVALID          # pitch < width
+
+
+def test_detection_slow_pass_gives_the_same_extrema(gpu_hip, monkeypatch):
+    """Strips with more candidates than the per-wave queue holds are re-done by the slow
+    instantiation of the detection kernel; shrinking the queue to 4 entries sends almost every
+    strip there, and the result must not change."""
+    img = synth(81, 400, 300)
+    ref = gpu_hip.Context().submit(img)
+    e0 = ref.extrema()
+    monkeypatch.setenv("POPSIFT_HIP_DET_QCAP", "4")
+    ctx = gpu_hip.Context()
+    e1 = ctx.submit(img).extrema()
+    monkeypatch.delenv("POPSIFT_HIP_DET_QCAP")
+    key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
+    assert len(e0) > 1000 and key(e0) == key(e1)

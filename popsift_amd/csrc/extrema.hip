@@ -258,7 +258,7 @@ __device__ bool refine(const DogView& dog, const SiftConsts& sc, int x, int y, i
  * below, and (with the centre excluded) of the own plane -- the strict 26-
  * neighbour test of s_extrema.cu:56-120 without any divergent load.
  */
-constexpr int DET_W = 62;
+constexpr int DET_W = 64;
 constexpr int DET_RH = 32;
 
 /* neighbour lane values through DPP wave shifts (VALU rate) instead of ds_bpermute (LDS
@@ -292,7 +292,7 @@ struct RowRed {
  * seen outside synthetic stress images; typical is ~50) is handed to the SLOW instantiation of this
  * kernel, which re-does it with a flush per row.
  */
-constexpr int DET_G = 8;   /* rows per load group */
+constexpr int DET_G = 4;   /* rows per load group */
 constexpr int DET_Q = 512; /* per-wave candidate queue (entries) */
 
 template <int MODE, int LEVELS, bool SLOW>
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         while (o + 1 < n_oct && unit >= pdp->o[o + 1].tile_begin) o++;
         const OctDesc od = pdp->o[o];
         const int     w = od.w, h = od.h;
-        const int     strips = (w - 2 + DET_W - 1) / DET_W;
+        const int     strips = (w - 2) / DET_W + 1; /* lanes cover x = 0 .. strips*64-1, candidates are 1 .. w-2 */
         const int     u = unit - od.tile_begin;
         const int     cy = u / strips, sx = u - cy * strips;
         const int     x = sx * DET_W + lane;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         const int     ye = min(yb + DET_RH - 1, h - 2);
         if (strips <= 0 || yb > ye) continue;
 
-        bool lane_ok = (lane >= 1 && lane <= DET_W && x <= w - 2);
+        bool lane_ok = (x >= 1 && x <= w - 2);
         if (MODE == POPSIFT_HIP_SIFT_OPENCV) lane_ok = lane_ok && (x >= 5 && x < w - 5);
 
         int       n_buf = 0;
@@ -346,21 +346,29 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             return 0;
         };
 
-        const float* base = arena + od.dog_off + xc;
+        /* left / centre / right neighbours are three overlapping row loads (same cache lines, the
+         * texture path sorts it out) rather than lane shifts: wave-wide DPP shifts turned out to
+         * stall the wave for tens of cycles each on gfx950 */
+        const float* base = arena + od.dog_off;
+        const int    xl = max(x - 1, 0), xr = min(x + 1, w - 1);
         RowRed<NP>   A, B, C;
         float        vB[NP], smx[NP], smn[NP];
 
         auto fetch_row = [&](int y, float* raw) {
             const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
-            for (int z = 0; z < NP; z++) raw[z] = p[z * od.plane_stride];
+            for (int z = 0; z < NP; z++) {
+                raw[3 * z + 0] = p[z * od.plane_stride + xc];
+                raw[3 * z + 1] = p[z * od.plane_stride + xl];
+                raw[3 * z + 2] = p[z * od.plane_stride + xr];
+            }
         };
         auto reduce_row = [&](const float* raw, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
 #pragma unroll
             for (int z = 0; z < NP; z++) {
-                const float c = raw[z];
-                const float l = lane_left(c);
-                const float r = lane_right(c);
+                const float c = raw[3 * z + 0];
+                const float l = raw[3 * z + 1];
+                const float r = raw[3 * z + 2];
                 v[z] = c;
                 sx_[z] = fmaxf(l, r);
                 sn_[z] = fminf(l, r);
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             }
         };
         {
-            float tv[NP], ts[NP], tn[NP], ra[NP], rb[NP];
+            float tv[NP], ts[NP], tn[NP], ra[3 * NP], rb[3 * NP];
             fetch_row(yb - 1, ra);
             fetch_row(yb, rb);
             reduce_row(ra, A, tv, ts, tn);
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         };
         if (SLOW) {
             for (int y = yb; y <= ye; y++) {
-                float q[NP];
+                float q[3 * NP];
                 fetch_row(y + 1, q);
                 step(y, q);
                 if (n_buf > QCAP - 64 * LEVELS) n_buf = flush(n_buf);
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             flush(n_buf);
         } else {
             for (int y0 = yb; y0 <= ye; y0 += DET_G) {
-                float q[DET_G][NP];
+                float q[DET_G][3 * NP];
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + k + 1, ye + 1), q[k]);
 #pragma unroll
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
 int extrema_units(int w, int h)
 {
     if (w < 3 || h < 3) return 0;
-    return ((w - 2 + DET_W - 1) / DET_W) * ((h - 2 + DET_RH - 1) / DET_RH);
+    return ((w - 2) / DET_W + 1) * ((h - 2 + DET_RH - 1) / DET_RH);
 }
 
 template <int MODE>

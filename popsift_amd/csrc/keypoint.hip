@@ -159,19 +159,39 @@ __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__
         const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
         const float inv_wx = 1.0f / (float)max(wx, 1);
 
+        /* software pipeline as in k_descriptor: request the taps of sample i+64 while binning sample i */
+        auto coord = [&](int i, int& xx, int& yy) {
+            const int row = (int)(((float)i + 0.5f) * inv_wx);
+            yy = row + ymin;
+            xx = i - row * wx + xmin;
+        };
+        int   xn = xmin, yn = ymin;
+        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+        if (loops > 0) {
+            coord(min(lane, loops - 1), xn, yn);
+            const float* c = layer + (__mul24(yn, pitch) + xn);
+            g0 = c[1];
+            g1 = c[-1];
+            g2 = c[pitch];
+            g3 = c[-pitch];
+        }
         for (int i = lane; i < loops; i += 64) {
-            const int    row = (int)(((float)i + 0.5f) * inv_wx);
-            const int    yy = row + ymin;
-            const int    xx = i - row * wx + xmin;
-            const float* c = layer + (__mul24(yy, pitch) + xx);
-            const float  gdx = c[1] - c[-1];
-            const float  gdy = c[pitch] - c[-pitch];
-            const float  grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
-            const float  theta = atan2_acc(gdy, gdx);
+            const int   xx = xn, yy = yn;
+            const float gdx = g0 - g1, gdy = g2 - g3;
+            {
+                coord(min(i + 64, loops - 1), xn, yn);
+                const float* c = layer + (__mul24(yn, pitch) + xn);
+                g0 = c[1];
+                g1 = c[-1];
+                g2 = c[pitch];
+                g3 = c[-pitch];
+            }
             const float dx = xx - x;
             const float dy = yy - y;
             const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
             if (sq_dist <= sq_thres) {
+                const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
+                const float theta = atan2_acc(gdy, gdx);
                 const float weight = grad * __expf(sq_dist * factor);
                 /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the reference's quotient only when
                  * the result is within an ulp of k + 0.5 */
@@ -518,7 +538,11 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
             const float inv_wx = 1.0f / (float)max(wx, 1);
             int         row = 0;
 
-            for (int i = lane; i < loops; i += 64) {
+            /* Two-stage software pipeline: the coordinates of sample i+64 are computed and its four
+             * gradient taps requested while sample i is being binned, so the L2 round trip of the taps
+             * (41 % of the wave cycles were spent waiting on it) overlaps the arithmetic.  The loads are
+             * unconditional (in-bounds for every span / box position) to keep the vmcnt waits counted. */
+            auto coord = [&](int i, int& off, float& u, float& v) {
                 int ii, jj;
                 if (spans) {
                     while (i >= rstart[row + 1]) row++;
@@ -532,12 +556,32 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
                 const float dx = jj - x, dy = ii - y;
                 /* position in cell units relative to the keypoint: cell (ix,iy) is centred
                  * at (ix-1.5, iy-1.5); n = u - off, dn = n + off = u (s_desc_loop.cu:88-99) */
-                const float u = fmaf(crsbp, dx, srsbp * dy);
-                const float v = fmaf(crsbp, dy, -srsbp * dx);
+                u = fmaf(crsbp, dx, srsbp * dy);
+                v = fmaf(crsbp, dy, -srsbp * dx);
+                off = __mul24(ii, pitch) + jj;
+            };
+            int   off_n = 0;
+            float u_n = 3.0f, v_n = 3.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+            if (loops > 0) {
+                coord(min(lane, loops - 1), off_n, u_n, v_n);
+                const float* c = layer + off_n;
+                g0 = c[1];
+                g1 = c[-1];
+                g2 = c[pitch];
+                g3 = c[-pitch];
+            }
+            for (int i = lane; i < loops; i += 64) {
+                const float u = u_n, v = v_n;
+                const float gx = g0 - g1, gy = g2 - g3;
+                {
+                    coord(min(i + 64, loops - 1), off_n, u_n, v_n);
+                    const float* c = layer + off_n;
+                    g0 = c[1];
+                    g1 = c[-1];
+                    g2 = c[pitch];
+                    g3 = c[-pitch];
+                }
                 if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
-                    const float* c = layer + (__mul24(ii, pitch) + jj);
-                    const float  gx = c[1] - c[-1];
-                    const float  gy = c[pitch] - c[-pitch];
                     const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
                     /* exp(-(u^2+v^2)/8) = 2^(-(u^2+v^2) * log2(e)/8) */
                     const float  ww = __builtin_amdgcn_exp2f(-0.18033688011112042f * (u * u + v * v));

@@ -158,7 +158,7 @@ oracle_ctx* oracle_create(const popsift_hip_params* p)
     if (p->gauss_mode != POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE &&
         p->gauss_mode != POPSIFT_HIP_GAUSS_OPENCV_COMPUTE)
         return NULL;
-    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP) return NULL;
+    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP && p->desc_mode != POPSIFT_HIP_DESC_GRID) return NULL;
     oracle_ctx* c = (oracle_ctx*)calloc(1, sizeof(*c));
     if (!c) return NULL;
     c->p = *p;
@@ -951,6 +951,89 @@ static void descriptor_one(const oracle_ctx* c, const ext_t* e, float ang, float
         }
 }
 
+/* point-texture read with clamp addressing (sift_octave.cu:233-235) */
+static inline float texv(const float* pl, int w, int h, int x, int y)
+{
+    return pl[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)];
+}
+
+/* s_desc_grid.cu:19-123 ext_desc_grid_sub, block (16,4,4): 16 lanes (xd) per cell, yd = 0..15.
+ * Every cell samples a fixed 16 x 16 grid of points of its own rotated unit square, snapped to
+ * the nearest pixel; the gradient comes from the int-coordinate texture overload of
+ * get_gradiant (s_gradiant.h:55-69, clamp addressing, no [1,w-2] clipping). */
+static void descriptor_grid_one(const oracle_ctx* c, const ext_t* e, float ang, float* features)
+{
+    const oct_t* oc = &c->oct[e->octave];
+    const int    width = oc->w, height = oc->h;
+    const float* layer = oc->data[clampi(e->lpos, 0, c->L - 1)];
+    const float  x = e->xpos, y = e->ypos, sig = e->sigma;
+    const float  SBP = fabsf(DESC_MAGNIFY * sig);
+    const float  M_4RPI = 4.0f / F_PI;
+
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (SBP == 0) return;
+
+    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+
+    for (int iy = 0; iy < 4; iy++)
+        for (int ix = 0; ix < 4; ix++) {
+            const int   tile = ((iy << 2) + ix) << 3;
+            const float offx = ix - 1.5f, offy = iy - 1.5f;
+            const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
+            const float pty = fmaf(csbp, offy, fmaf(ssbp, offx, y));
+            const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t;       /* lft_dn */
+            const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;           /* rgt_stp */
+            const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;          /* up__stp */
+            float       dpt[16][9];
+            memset(dpt, 0, sizeof(dpt));
+            for (int xd = 0; xd < 16; xd++) {
+                for (int yd = 0; yd < 16; yd++) {
+                    /* pixo = lft_dn + (xd+0.5)*rgt_stp + (yd+0.5)*up__stp (left to right) */
+                    float pixox = ldx + (xd + 0.5f) * rsx + (yd + 0.5f) * usx;
+                    float pixoy = ldy + (xd + 0.5f) * rsy + (yd + 0.5f) * usy;
+                    float pixx = pixox * SBP, pixy = pixoy * SBP;
+                    pixx = roundf(ptx + pixx) - ptx;
+                    pixy = roundf(pty + pixy) - pty;
+                    pixox = pixx / SBP;
+                    pixoy = pixy / SBP;
+                    /* get_gradiant( mod, th, (pt+pix).x, (pt+pix).y, ... ): float -> int truncation */
+                    const int   gx = (int)(ptx + pixx), gy = (int)(pty + pixy);
+                    const float dxv = texv(layer, width, height, gx + 1, gy) - texv(layer, width, height, gx - 1, gy);
+                    const float dyv = texv(layer, width, height, gx, gy + 1) - texv(layer, width, height, gx, gy - 1);
+                    const float mod = hypotf(dxv, dyv);
+                    float       th = atan2f(dyv, dxv);
+                    const float npx = fmaf(cos_t, pixox, sin_t * pixoy);
+                    const float npy = fmaf(cos_t, pixoy, -sin_t * pixox);
+                    const float dnx = npx + offx, dny = npy + offy;
+                    const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));
+                    const float wx_ = 1.0f - fabsf(npx), wy_ = 1.0f - fabsf(npy);
+                    if (wx_ < 0.0f || wy_ < 0.0f) continue;
+                    const float wgt = ww * wx_ * wy_ * mod;
+                    th -= ang;
+                    th += (th < 0.0f ? F_PI2 : 0.0f);
+                    th -= (th >= F_PI2 ? F_PI2 : 0.0f);
+                    const float tth = mul_up(th, M_4RPI);
+                    const int   fo0 = (int)floorf(tth);
+                    const float do0 = tth - fo0;
+                    int         fo = fo0 % 8;
+                    if (fo < 0) fo = 0;
+                    dpt[xd][fo] = fma_up(1.0f - do0, wgt, dpt[xd][fo]);
+                    dpt[xd][fo + 1] = fma_up(do0, wgt, dpt[xd][fo + 1]);
+                }
+                dpt[xd][0] += dpt[xd][8];
+            }
+            /* shuffle_down 8, 4, 2, 1 within 16 lanes; lane 0 */
+            for (int b = 0; b < 8; b++) {
+                float v[16];
+                for (int l = 0; l < 16; l++) v[l] = dpt[l][b];
+                for (int s = 8; s >= 1; s >>= 1)
+                    for (int l = 0; l < s; l++) v[l] += v[l + s];
+                features[tile + b] = v[0];
+            }
+        }
+}
+
 /* s_desc_norm_rs.h:44-79 / s_desc_norm_l2.h:87-134 (32 lanes x float4, tree sums) */
 static float tree_sum32(const float* lane)
 {
@@ -1014,7 +1097,10 @@ static int keypoint_stages(oracle_ctx* c)
         for (int k = 0; k < e->num_ori; k++) {
             float* raw = c->desc_raw + 128 * (size_t)(e->idx_ori + k);
             float* out = c->desc + 128 * (size_t)(e->idx_ori + k);
-            descriptor_one(c, e, e->orientation[k], raw);
+            if (c->p.desc_mode == POPSIFT_HIP_DESC_GRID)
+                descriptor_grid_one(c, e, e->orientation[k], raw);
+            else
+                descriptor_one(c, e, e->orientation[k], raw);
             memcpy(out, raw, 128 * sizeof(float));
             oracle_normalize(out, c->p.norm_mode, c->norm_multi);
         }

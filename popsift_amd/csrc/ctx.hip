@@ -171,6 +171,7 @@ void init_tables(popsift_hip_ctx* c)
     sc.sift_mode = p.sift_mode;
     sc.grid_size = p.filter_grid_size > 0 ? p.filter_grid_size : 1;
     sc.up_fac_int = (int)p.upscale_factor;
+    sc.desc_mode = p.desc_mode;
     {
         const char* e = getenv("POPSIFT_HIP_DET_QCAP"); /* test hook: force strips into the slow detection pass */
         sc.det_qcap = e ? std::max(atoi(e), 0) : (1 << 30);
@@ -574,7 +575,7 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
     if (p->levels > POPSIFT_HIP_MAX_LEVELS - 3) return POPSIFT_HIP_ERR_INVALID;
     if (p->gauss_mode != POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE && p->gauss_mode != POPSIFT_HIP_GAUSS_OPENCV_COMPUTE)
         return POPSIFT_HIP_ERR_INVALID;
-    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP) return POPSIFT_HIP_ERR_INVALID;
+    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP && p->desc_mode != POPSIFT_HIP_DESC_GRID) return POPSIFT_HIP_ERR_INVALID;
     if (p->sift_mode < 0 || p->sift_mode > 2 || p->norm_mode < 0 || p->norm_mode > 1) return POPSIFT_HIP_ERR_INVALID;
     if (p->max_extrema < 1 || !(p->edge_limit > 0.0f)) return POPSIFT_HIP_ERR_INVALID;
     int n = 0;

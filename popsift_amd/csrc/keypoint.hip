@@ -666,6 +666,135 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
     }
 }
 
+/* --------------------------------------------------------- descriptor: grid */
+
+/*
+ * DescMode Grid (s_desc_grid.cu:19-147): every cell samples a FIXED 16 x 16 grid of points of its
+ * own rotated unit square, each snapped to the nearest pixel, and bins only into its own 8
+ * orientation bins.  The reference runs a (16,4,4) block per descriptor: 16 lanes per cell, each
+ * looping over 16 rows.  Here one wave owns a descriptor and visits the cells one after the other
+ * with all 64 lanes (4 grid rows x 16 columns per step); bins are accumulated in registers with
+ * predicated adds and summed over the wave by a butterfly -- no atomics, fixed summation order.
+ * The position arithmetic follows the reference operation by operation (the float -> int
+ * truncation of "pt + (round(pt + pix) - pt)" included), so the sampled pixels are the oracle's.
+ */
+__global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restrict__ pdp,
+                                                         const float* __restrict__ arena, SiftConsts sc,
+                                                         const Counters* __restrict__ ct,
+                                                         const Ext* __restrict__ ext, const int* __restrict__ map,
+                                                         float* __restrict__ desc, int desc_cap)
+{
+    __shared__ float s_feat[4][128];
+    const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float*           feat = s_feat[wave];
+    const int        total = min(ct->ori_total, desc_cap);
+    const int        L = pdp->L;
+    const float      M_4RPI = 4.0f / F_PI;
+    const int        xd = lane & 15, ysub = lane >> 4;
+
+    for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
+        const Ext*     e = ext + map[d];
+        const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
+        const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
+        const float    ang = e->orientation[ko];
+        const OctDesc* od = &pdp->o[e->octave];
+        const int      width = od->w, height = od->h, pitch = od->pitch;
+        const int      lvl = min(max(e->lpos, 0), L - 1);
+        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
+        const float    SBP = fabsf(DESC_MAGNIFY * sigma);
+
+        feat[lane] = 0.0f;
+        feat[lane + 64] = 0.0f;
+        if (SBP != 0.0f) {
+            float sin_t, cos_t;
+            sincosf(ang, &sin_t, &cos_t);
+            const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+            const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t; /* lft_dn  */
+            const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;     /* rgt_stp */
+            const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;    /* up__stp */
+            for (int cell = 0; cell < 16; cell++) {
+                const int   ix = cell & 3, iy = cell >> 2;
+                const float offx = ix - 1.5f, offy = iy - 1.5f;
+                const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
+                const float pty = fmaf(csbp, offy, fmaf(ssbp, offx, y));
+                float       acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int step = 0; step < 4; step++) {
+                    const int yd = step * 4 + ysub;
+                    float     pixox = ldx + (xd + 0.5f) * rsx + (yd + 0.5f) * usx;
+                    float     pixoy = ldy + (xd + 0.5f) * rsy + (yd + 0.5f) * usy;
+                    float     pixx = pixox * SBP, pixy = pixoy * SBP;
+                    pixx = roundf(ptx + pixx) - ptx;
+                    pixy = roundf(pty + pixy) - pty;
+                    pixox = pixx / SBP;
+                    pixoy = pixy / SBP;
+                    const int    gx = (int)(ptx + pixx), gy = (int)(pty + pixy);
+                    /* point texture, clamp addressing */
+                    const int    xc = min(max(gx, 0), width - 1), yc = min(max(gy, 0), height - 1);
+                    const int    xl = min(max(gx - 1, 0), width - 1), xr = min(max(gx + 1, 0), width - 1);
+                    const int    yu = min(max(gy - 1, 0), height - 1), yl = min(max(gy + 1, 0), height - 1);
+                    const float* rowc = layer + __mul24(yc, pitch);
+                    const float  dxv = rowc[xr] - rowc[xl];
+                    const float  dyv = layer[__mul24(yl, pitch) + xc] - layer[__mul24(yu, pitch) + xc];
+                    const float  mod = __builtin_amdgcn_sqrtf(dxv * dxv + dyv * dyv);
+                    float        th = atan2_acc(dyv, dxv);
+                    const float  npx = fmaf(cos_t, pixox, sin_t * pixoy);
+                    const float  npy = fmaf(cos_t, pixoy, -sin_t * pixox);
+                    const float  dnx = npx + offx, dny = npy + offy;
+                    const float  ww = __expf(-0.125f * (dnx * dnx + dny * dny));
+                    const float  wx_ = 1.0f - fabsf(npx), wy_ = 1.0f - fabsf(npy);
+                    const float  wgt = (wx_ < 0.0f || wy_ < 0.0f) ? 0.0f : ww * wx_ * wy_ * mod;
+                    th -= ang;
+                    th += (th < 0.0f ? F_PI2 : 0.0f);
+                    th -= (th >= F_PI2 ? F_PI2 : 0.0f);
+                    const float tth = th * M_4RPI;
+                    const float ffo = floorf(tth);
+                    const float do0 = tth - ffo;
+                    const int   b0 = (int)ffo & 7, b1 = (b0 + 1) & 7;
+                    const float w1 = do0 * wgt, w0 = wgt - w1;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) acc[b] += (b == b0 ? w0 : 0.0f) + (b == b1 ? w1 : 0.0f);
+                }
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    float v = acc[b];
+#pragma unroll
+                    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+                    if (lane == 0) feat[(cell << 3) + b] = v;
+                }
+            }
+        }
+        wave_lds_sync();
+
+        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
+        float v0 = feat[lane], v1 = feat[lane + 64];
+        if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
+            float sum = v0 + v1;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            v0 = scalbnf(sqrtf(v0 / sum), sc.norm_multi);
+            v1 = scalbnf(sqrtf(v1 / sum), sc.norm_multi);
+        } else {
+            float sq = v0 * v0 + v1 * v1;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            const float norm = sqrtf(sq);
+            v0 = fminf(v0, 0.2f * norm);
+            v1 = fminf(v1, 0.2f * norm);
+            sq = v0 * v0 + v1 * v1;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            float rn = 1.0f / sqrtf(sq);
+            rn = scalbnf(rn, sc.norm_multi);
+            v0 = v0 * rn;
+            v1 = v1 * rn;
+        }
+        desc[(size_t)d * 128 + lane] = v0;
+        desc[(size_t)d * 128 + 64 + lane] = v1;
+        wave_lds_sync();
+    }
+}
+
 /* --------------------------------------------------------------- features */
 
 __global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __restrict__ ct,
@@ -714,7 +843,10 @@ int scan_chunk() { return SCAN_CHUNK; }
 hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
                               const Ext* ext, const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+    if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
+        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+    else
+        hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     return hipGetLastError();
 }
 

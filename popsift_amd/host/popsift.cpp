@@ -142,7 +142,8 @@ bool PopSift::configure(const popsift::Config& config, bool /*force*/)
     if (_config.getGaussMode() != popsift::Config::VLFeat_Compute &&
         _config.getGaussMode() != popsift::Config::OpenCV_Compute)
         DIE("this build implements the Gauss modes 'vlfeat' and 'opencv' only");
-    if (_config.getDescMode() != popsift::Config::Loop) DIE("this build implements the descriptor mode 'loop' only");
+    if (_config.getDescMode() != popsift::Config::Loop && _config.getDescMode() != popsift::Config::Grid)
+        DIE("this build implements the descriptor modes 'loop' and 'grid' only");
     if (_config.getScalingMode() != popsift::Config::ScaleDefault) DIE("ScaleDirect is not supported");
     _shadow_config = _config;
     return true;

@@ -32,6 +32,8 @@ CASES = [
     ("tiny_17x13", dict(), (20, 17, 13)),
     ("thin_300x9", dict(), (25, 300, 9)),
     ("edge_limit_threshold", dict(edge_limit=5.0, threshold=0.08), (26, 256, 192)),
+    ("grid_descriptor", dict(desc_mode=2), (28, 240, 180)),
+    ("grid_descriptor_vlfeat_classic", dict(desc_mode=2, sift_mode=2, norm_mode=1), (29, 200, 150)),
 ]
 
 
@@ -53,7 +55,7 @@ def assert_planes_equal(orc, ctx, levels):
                     o, kind, l, int((bits(a) != bits(b)).sum()), float(np.abs(a - b).max()))
 
 
-def assert_keypoints_match(orc, ctx):
+def assert_keypoints_match(orc, ctx, grid_mode=False):
     eo, eh = orc.extrema(), ctx.extrema()
     key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
     assert key(eo) == key(eh)                       # same set, bit-exact positions
@@ -65,9 +67,17 @@ def assert_keypoints_match(orc, ctx):
     assert st["max_sigma_rel"] < 1e-5
     n = max(st["n_desc"], 1)
     assert st["num_ori_diff"] <= max(1, st["n_a"] // 2000)
-    assert st["desc_bad"] <= max(1, n // 500), st
     assert st["ang_bad"] <= max(1, n // 500), st
-    assert st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2, st
+    if grid_mode:
+        # DescMode Grid snaps each of its 4096 sample points per descriptor to the nearest pixel
+        # (s_desc_grid.cu:77): an ulp of difference in sin/cos (device vs host libm; the reference's
+        # own __sincosf is far coarser) moves a point across a .5 boundary in a few percent of the
+        # descriptors and swaps one of the 256 samples of a cell.  Most stay within 1e-3.
+        assert st["desc_bad"] <= n // 15, st
+        assert st["max_desc"] < 6e-2 and st["max_ang"] < 3e-2, st
+    else:
+        assert st["desc_bad"] <= max(1, n // 500), st
+        assert st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2, st
     # layout contract of the reference: descriptors feature by feature, octaves ascending
     idx = np.concatenate([f["desc_idx"][: int(f["num_ori"])] for f in fh]) if len(fh) else np.zeros(0, int)
     assert np.array_equal(idx, np.arange(len(dh)))
@@ -80,7 +90,7 @@ def test_hip_matches_oracle(oracle_mod, gpu_hip, name, kw, spec):
     img = synth(*spec)
     orc, ctx = run_both(oracle_mod, gpu_hip, kw, img)
     assert_planes_equal(orc, ctx, max(2, kw.get("levels", 3)))
-    assert_keypoints_match(orc, ctx)
+    assert_keypoints_match(orc, ctx, grid_mode=(kw.get("desc_mode", 0) == 2))
     ctx.close()
 
 

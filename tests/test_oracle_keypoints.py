@@ -141,3 +141,18 @@ def test_max_extrema_caps_each_octave(oracle_mod):
     o = O.Oracle(O.default_params(max_extrema=50)).run(img)
     assert max(o.ext_counts()) == 50
     assert o.counts()[0] == sum(o.ext_counts())
+
+
+def test_grid_descriptor_mode(oracle_mod):
+    """DescMode Grid (s_desc_grid.cu): same keypoints and orientations as Loop, a descriptor sampled
+    on a fixed 16x16 grid per cell -- close to the Loop descriptor, normalised the same way."""
+    O = oracle_mod
+    img = synth(8, 200, 150)
+    fa, da = O.Oracle(O.default_params()).run(img).fetch()
+    fb, db = O.Oracle(O.default_params(desc_mode=2)).run(img).fetch()
+    assert np.array_equal(fa, fb)                     # descriptors do not feed back into keypoints
+    assert db.shape == da.shape and np.all(db >= 0)
+    np.testing.assert_allclose((db.astype(np.float64) ** 2).sum(1), 1.0, rtol=2e-4)
+    cos = np.sum(da * db, axis=1)                     # both RootSift-normalised: unit vectors
+    assert np.median(cos) > 0.98 and cos.min() > 0.6
+    assert not np.allclose(da, db)

@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="images in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="images in flight per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context roofline pass (the command profiles/ *_roofline_pass* was taken with)")

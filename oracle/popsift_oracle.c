@@ -158,7 +158,9 @@ oracle_ctx* oracle_create(const popsift_hip_params* p)
     if (p->gauss_mode != POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE &&
         p->gauss_mode != POPSIFT_HIP_GAUSS_OPENCV_COMPUTE)
         return NULL;
-    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP && p->desc_mode != POPSIFT_HIP_DESC_GRID) return NULL;
+    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP && p->desc_mode != POPSIFT_HIP_DESC_GRID &&
+        p->desc_mode != POPSIFT_HIP_DESC_NOTILE)
+        return NULL;
     oracle_ctx* c = (oracle_ctx*)calloc(1, sizeof(*c));
     if (!c) return NULL;
     c->p = *p;
@@ -1034,6 +1036,93 @@ static void descriptor_grid_one(const oracle_ctx* c, const ext_t* e, float ang, 
         }
 }
 
+/* linear-filter texture read of a plane at pixel-centre coordinates (readTex adds the +0.5 that
+ * CUDA's unnormalised linear filter subtracts again, common/assist.h:66-81): bilinear between
+ * the four surrounding pixels, clamp addressing, 1.8 fixed-point weights */
+static inline float tex_linear(const float* pl, int w, int h, float x, float y)
+{
+    const float fx = floorf(x), fy = floorf(y);
+    float       a = x - fx, b = y - fy;
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const int   i = (int)fx, j = (int)fy;
+    const float t00 = texv(pl, w, h, i, j), t10 = texv(pl, w, h, i + 1, j);
+    const float t01 = texv(pl, w, h, i, j + 1), t11 = texv(pl, w, h, i + 1, j + 1);
+    const float top = (1.0f - a) * t00 + a * t10;
+    const float bot = (1.0f - a) * t01 + a * t11;
+    return (1.0f - b) * top + b * bot;
+}
+
+/* s_desc_notile.cu:28-99 ext_desc_notile_sub, block (32,4,1), with the tables of
+ * sift_constants.cu:33-47 (desc_gauss[40][40], desc_tile[16]) and the rotated, interpolated
+ * gradient of s_gradiant.h:71-87.  Cell (cellx, out_y) is owned by the 8 lanes tx = 8*cellx+in_x;
+ * each lane visits 2 x 16 of the cell's 16 x 16 sample points; lanes are summed with
+ * shuffle_down 4, 2, 1. */
+static void descriptor_notile_one(const oracle_ctx* c, const ext_t* e, float ang, float* features)
+{
+    const oct_t* oc = &c->oct[e->octave];
+    const int    width = oc->w, height = oc->h;
+    const float* layer = oc->data[clampi(e->lpos, 0, c->L - 1)];
+    const float  x = e->xpos, y = e->ypos;
+    const float  SBP = fabsf(DESC_MAGNIFY * e->sigma);
+    const float  M_4RPI = 4.0f / F_PI;
+    const float  stepbase = -2.5f + 1.0f / 16.0f;
+
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (e->sigma == 0) return;
+    const float cos_t = cosf(ang), sin_t = sinf(ang);
+
+    float desc_tile[16];
+    for (int i = 0; i < 16; i++) desc_tile[i] = 1.0f - fabsf(-1.0f + 1.0f / 16.0f + i * 1.0f / 8.0f);
+    const float dn_step = 1.0f / 8.0f, dn_base = 0.5f * dn_step - 20.0f * dn_step;
+
+    for (int out_y = 0; out_y < 4; out_y++)
+        for (int cellx = 0; cellx < 4; cellx++) {
+            float dpt[8][8];
+            memset(dpt, 0, sizeof(dpt));
+            for (int in_x = 0; in_x < 8; in_x++) {
+                const int tx = 8 * cellx + in_x;
+                for (int xoff = 0; xoff < 2; xoff++) {
+                    const int xd = (xoff << 3) + in_x;
+                    const int newx = (xoff << 3) + tx;
+                    for (int yoff = 0; yoff < 2; yoff++)
+                        for (int in_y = 0; in_y < 8; in_y++) {
+                            const int   yd = (yoff << 3) + in_y;
+                            const int   newy = (out_y << 3) + yd;
+                            const float wgt = desc_tile[xd] * desc_tile[yd];
+                            const float stepx = stepbase + scalbnf((float)newx, -3);
+                            const float stepy = stepbase + scalbnf((float)newy, -3);
+                            const float ptx = cos_t * stepx + -sin_t * stepy;
+                            const float pty = cos_t * stepy + sin_t * stepx;
+                            const float px = x + ptx * SBP, py = y + pty * SBP;
+                            const float dxv = tex_linear(layer, width, height, px + cos_t, py + sin_t) -
+                                              tex_linear(layer, width, height, px - cos_t, py - sin_t);
+                            const float dyv = tex_linear(layer, width, height, px - sin_t, py + cos_t) -
+                                              tex_linear(layer, width, height, px + sin_t, py - cos_t);
+                            const float mod = hypotf(dxv, dyv);
+                            float       th = atan2f(dyv, dxv);
+                            th += (th < 0.0f ? F_PI2 : 0.0f);
+                            const float tth = th * M_4RPI;
+                            const int   fo = (int)floorf(th * M_4RPI);
+                            const float do0 = tth - fo;
+                            const int   fo0 = fo & 7, fo1 = (fo0 + 1) & 7;
+                            const float dnx = dn_base + newx * dn_step, dny = dn_base + newy * dn_step;
+                            const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3)) * mod; /* desc_gauss */
+                            dpt[in_x][fo0] += (wgt * ((1.0f - do0) * ww));
+                            dpt[in_x][fo1] += (wgt * (do0 * ww));
+                        }
+                }
+            }
+            for (int b = 0; b < 8; b++) {
+                float v[8];
+                for (int l = 0; l < 8; l++) v[l] = dpt[l][b];
+                for (int s = 4; s >= 1; s >>= 1)
+                    for (int l = 0; l < s; l++) v[l] += v[l + s];
+                features[((out_y << 2) + cellx) * 8 + b] = v[0];
+            }
+        }
+}
+
 /* s_desc_norm_rs.h:44-79 / s_desc_norm_l2.h:87-134 (32 lanes x float4, tree sums) */
 static float tree_sum32(const float* lane)
 {
@@ -1099,6 +1188,8 @@ static int keypoint_stages(oracle_ctx* c)
             float* out = c->desc + 128 * (size_t)(e->idx_ori + k);
             if (c->p.desc_mode == POPSIFT_HIP_DESC_GRID)
                 descriptor_grid_one(c, e, e->orientation[k], raw);
+            else if (c->p.desc_mode == POPSIFT_HIP_DESC_NOTILE)
+                descriptor_notile_one(c, e, e->orientation[k], raw);
             else
                 descriptor_one(c, e, e->orientation[k], raw);
             memcpy(out, raw, 128 * sizeof(float));

@@ -795,6 +795,151 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
     }
 }
 
+/* ------------------------------------------------------- descriptor: notile */
+
+/* linear-filter read at pixel-centre coordinates, clamp addressing, 1.8 fixed-point weights
+ * (what tex2DLayered on the reference's linear texture returns, common/assist.h:66-81) */
+__device__ __forceinline__ float tex_linear(const float* pl, int w, int h, int pitch, float x, float y)
+{
+    const float fx = floorf(x), fy = floorf(y);
+    float       a = x - fx, b = y - fy;
+    a = floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const int    i = (int)fx, j = (int)fy;
+    const int    x0 = min(max(i, 0), w - 1), x1 = min(max(i + 1, 0), w - 1);
+    const float* r0 = pl + __mul24(min(max(j, 0), h - 1), pitch);
+    const float* r1 = pl + __mul24(min(max(j + 1, 0), h - 1), pitch);
+    const float  top = (1.0f - a) * r0[x0] + a * r0[x1];
+    const float  bot = (1.0f - a) * r1[x0] + a * r1[x1];
+    return (1.0f - b) * top + b * bot;
+}
+
+/*
+ * DescMode NoTile (s_desc_notile.cu:28-128): a 40 x 40 grid of sample points at 1/8-cell pitch in
+ * the keypoint's rotated frame; at each point the gradient is taken along the rotated axes from
+ * four bilinearly interpolated reads (s_gradiant.h:71-87), weighted by a Gaussian table
+ * (desc_gauss, sift_constants.cu:33-41) and by tent weights over the 16 x 16 points of every cell
+ * that covers it (desc_tile, :43-46).  The reference evaluates each point once per covering
+ * cell (up to four times); here one wave owns the descriptor, evaluates each of the 1600 points
+ * once and spreads it to its <= 2 x 2 cells with the packed fixed-point LDS atomics of the loop
+ * kernel.
+ */
+__global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __restrict__ pdp,
+                                                           const float* __restrict__ arena, SiftConsts sc,
+                                                           const Counters* __restrict__ ct,
+                                                           const Ext* __restrict__ ext, const int* __restrict__ map,
+                                                           float* __restrict__ desc, int desc_cap)
+{
+    constexpr int    DCOPY = 2;
+    constexpr int    FBITS = 14; /* 256 points per cell, each <= 361 * 1: low halves stay below 2^32 */
+    __shared__ fix64 s_hist[4][DCOPY][128];
+    const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    fix64*           hist = s_hist[wave][lane & (DCOPY - 1)];
+    fix64*           hall = s_hist[wave][0];
+    const int        total = min(ct->ori_total, desc_cap);
+    const int        L = pdp->L;
+    const float      M_4RPI = 4.0f / F_PI;
+    const float      stepbase = -2.5f + 1.0f / 16.0f;
+    const float      fscale = (float)(1 << FBITS);
+
+    for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
+        const Ext*     e = ext + map[d];
+        const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
+        const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
+        const float    ang = e->orientation[ko];
+        const OctDesc* od = &pdp->o[e->octave];
+        const int      width = od->w, height = od->h, pitch = od->pitch;
+        const int      lvl = min(max(e->lpos, 0), L - 1);
+        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
+        const float    SBP = fabsf(DESC_MAGNIFY * sigma);
+
+#pragma unroll
+        for (int k = 0; k < 2 * DCOPY; k++) hall[lane + 64 * k] = 0ull;
+        wave_lds_sync();
+
+        if (sigma != 0.0f) {
+            float sin_t, cos_t;
+            sincosf(ang, &sin_t, &cos_t);
+            for (int p = lane; p < 1600; p += 64) {
+                const int   newy = p / 40, newx = p - newy * 40;
+                const float stepx = stepbase + 0.125f * (float)newx;
+                const float stepy = stepbase + 0.125f * (float)newy;
+                const float ptx = cos_t * stepx + -sin_t * stepy;
+                const float pty = cos_t * stepy + sin_t * stepx;
+                const float px = x + ptx * SBP, py = y + pty * SBP;
+                const float dxv = tex_linear(layer, width, height, pitch, px + cos_t, py + sin_t) -
+                                  tex_linear(layer, width, height, pitch, px - cos_t, py - sin_t);
+                const float dyv = tex_linear(layer, width, height, pitch, px - sin_t, py + cos_t) -
+                                  tex_linear(layer, width, height, pitch, px + sin_t, py - cos_t);
+                const float mod = __builtin_amdgcn_sqrtf(dxv * dxv + dyv * dyv);
+                float       th = atan2_acc(dyv, dxv);
+                th += (th < 0.0f ? F_PI2 : 0.0f);
+                const float tth = th * M_4RPI;
+                const float ffo = floorf(tth);
+                const float do0 = tth - ffo;
+                const int   b0 = (int)ffo & 7;
+                /* desc_gauss[newy][newx]: exp(-(dnx^2 + dny^2) / 8), dn = step position */
+                const float ww = __expf(-0.125f * (stepx * stepx + stepy * stepy)) * mod * fscale;
+                const float a1 = do0 * ww, a0 = ww - a1;
+                /* cells cx with 8cx <= newx <= 8cx+15, tent weight desc_tile[newx - 8cx] */
+#pragma unroll
+                for (int jy = 0; jy < 2; jy++) {
+                    const int cy = (newy >> 3) - jy;
+                    if (cy < 0 || cy > 3) continue;
+                    const float wy = 1.0f - fabsf(-1.0f + 1.0f / 16.0f + 0.125f * (float)(newy - 8 * cy));
+#pragma unroll
+                    for (int jx = 0; jx < 2; jx++) {
+                        const int cx = (newx >> 3) - jx;
+                        if (cx < 0 || cx > 3) continue;
+                        const float wx = 1.0f - fabsf(-1.0f + 1.0f / 16.0f + 0.125f * (float)(newx - 8 * cx));
+                        const float wgt = wx * wy;
+                        const unsigned int lo = (unsigned int)fmaf(a0, wgt, 0.5f);
+                        const unsigned int hi = (unsigned int)fmaf(a1, wgt, 0.5f);
+                        atomicAdd(&hist[((((cy << 2) + cx) << 3)) + b0], ((fix64)hi << 32) | lo);
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+
+        /* bin b of a cell = low half of word b + high half of word b-1 (mod 8), over the copies */
+        fix64     a0 = 0ull, a1 = 0ull;
+        const int prevw = (lane & ~7) | ((lane + 7) & 7);
+#pragma unroll
+        for (int k = 0; k < DCOPY; k++) {
+            a0 += (hall[k * 128 + lane] & 0xffffffffull) + (hall[k * 128 + prevw] >> 32);
+            a1 += (hall[k * 128 + lane + 64] & 0xffffffffull) + (hall[k * 128 + prevw + 64] >> 32);
+        }
+        float v0 = (float)a0 * (1.0f / (float)(1 << FBITS)), v1 = (float)a1 * (1.0f / (float)(1 << FBITS));
+
+        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
+        if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
+            float sum = v0 + v1;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            v0 = scalbnf(sqrtf(v0 / sum), sc.norm_multi);
+            v1 = scalbnf(sqrtf(v1 / sum), sc.norm_multi);
+        } else {
+            float sq = v0 * v0 + v1 * v1;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            const float norm = sqrtf(sq);
+            v0 = fminf(v0, 0.2f * norm);
+            v1 = fminf(v1, 0.2f * norm);
+            sq = v0 * v0 + v1 * v1;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            float rn = 1.0f / sqrtf(sq);
+            rn = scalbnf(rn, sc.norm_multi);
+            v0 = v0 * rn;
+            v1 = v1 * rn;
+        }
+        desc[(size_t)d * 128 + lane] = v0;
+        desc[(size_t)d * 128 + 64 + lane] = v1;
+        wave_lds_sync();
+    }
+}
+
 /* --------------------------------------------------------------- features */
 
 __global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __restrict__ ct,
@@ -843,7 +988,9 @@ int scan_chunk() { return SCAN_CHUNK; }
 hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
                               const Ext* ext, const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
 {
-    if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
+    if (sc.desc_mode == POPSIFT_HIP_DESC_NOTILE)
+        hipLaunchKernelGGL(k_descriptor_notile, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+    else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
         hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     else
         hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);

@@ -34,6 +34,8 @@ CASES = [
     ("edge_limit_threshold", dict(edge_limit=5.0, threshold=0.08), (26, 256, 192)),
     ("grid_descriptor", dict(desc_mode=2), (28, 240, 180)),
     ("grid_descriptor_vlfeat_classic", dict(desc_mode=2, sift_mode=2, norm_mode=1), (29, 200, 150)),
+    ("notile_descriptor", dict(desc_mode=4), (30, 240, 180)),
+    ("notile_descriptor_opencv_classic", dict(desc_mode=4, sift_mode=1, norm_mode=1, norm_multi=9), (31, 200, 150)),
 ]
 
 

@@ -156,3 +156,17 @@ def test_grid_descriptor_mode(oracle_mod):
     cos = np.sum(da * db, axis=1)                     # both RootSift-normalised: unit vectors
     assert np.median(cos) > 0.98 and cos.min() > 0.6
     assert not np.allclose(da, db)
+
+
+def test_notile_descriptor_mode(oracle_mod):
+    """DescMode NoTile (s_desc_notile.cu): 40x40 interpolated sample grid in the rotated frame."""
+    O = oracle_mod
+    img = synth(8, 200, 150)
+    fa, da = O.Oracle(O.default_params()).run(img).fetch()
+    fb, db = O.Oracle(O.default_params(desc_mode=4)).run(img).fetch()
+    assert np.array_equal(fa, fb)
+    assert db.shape == da.shape and np.all(db >= 0)
+    np.testing.assert_allclose((db.astype(np.float64) ** 2).sum(1), 1.0, rtol=2e-4)
+    cos = np.sum(da * db, axis=1)
+    assert np.median(cos) > 0.995 and cos.min() > 0.6
+    assert not np.allclose(da, db)

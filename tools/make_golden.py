@@ -21,6 +21,7 @@ CASES = {
     "opencv_classic_97x75": (dict(sift_mode=1, gauss_mode=3, norm_mode=1, norm_multi=9), synth(23, 97, 75)),
     "noupscale_levels4_150x110": (dict(upscale_factor=0.0, levels=4), synth(24, 150, 110)),
     "grid_desc_90x70": (dict(desc_mode=2), synth(25, 90, 70)),
+    "notile_desc_90x70": (dict(desc_mode=4), synth(26, 90, 70)),
 }
 
 if __name__ == "__main__":

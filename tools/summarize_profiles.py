@@ -17,7 +17,7 @@ def short(n):
 
 
 def stats(sub):
-    f = glob.glob(os.path.join(RAW, sub, "**", "*kernel_stats.csv"), recursive=True)[0]
+    f = sorted(glob.glob(os.path.join(RAW, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
     rows = list(csv.DictReader(open(f)))
     lines = ["%-44s %7s %12s %11s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
     for r in rows:
@@ -27,7 +27,7 @@ def stats(sub):
 
 
 def timeline(sub, nimg):
-    f = glob.glob(os.path.join(RAW, sub, "**", "*kernel_trace.csv"), recursive=True)[0]
+    f = sorted(glob.glob(os.path.join(RAW, sub, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     last = rows[-(len(rows) // nimg):]
     t0 = int(last[0]["Start_Timestamp"])
@@ -44,7 +44,7 @@ def timeline(sub, nimg):
 
 
 def pmc(sub, counter, nimg):
-    f = glob.glob(os.path.join(RAW, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = sorted(glob.glob(os.path.join(RAW, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1]
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -61,7 +61,7 @@ if __name__ == "__main__":
     bench_line = [l for l in open(os.path.join(RAW, "bench.log")).read().splitlines() if l.startswith('{"metric"')][-1]
     open(os.path.join(OUT, "%s_bench_kernel_stats.txt" % TAG), "w").write(
         "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline\n"
-        "# (8 contexts in flight, 1 MI355X; includes warm-up, the latency and the profile-mode passes)\n"
+        "# (16 contexts in flight, 1 MI355X; includes warm-up, the latency and the profile-mode passes)\n"
         + txt + "\n\n# bench.py output of this profiled run:\n" + bench_line + "\n")
     _, txt = stats("roofline")
     rl = [l for l in open(os.path.join(RAW, "roofline.log")).read().splitlines() if l.startswith('{"metric"')][-1]

@@ -100,7 +100,7 @@ struct Config {
     int   getNormalizationMultiplier() const { return _normalization_multiplier; }
     float getUpscaleFactor() const { return _upscale_factor; }
     int   getMaxExtrema() const { return _max_extrema; }
-    bool  getCanFilterExtrema() const { return false; } /* grid filter is not part of this build */
+    bool  getCanFilterExtrema() const { return true; } /* sift_conf.h:183: false only for CUDA < 8 builds */
     int   getFilterMaxExtrema() const { return _filter_max_extrema; }
     int   getFilterGridSize() const { return _filter_grid_size; }
     GridFilterMode getFilterSorting() const { return _grid_filter_mode; }

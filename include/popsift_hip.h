@@ -46,6 +46,8 @@ enum { POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE = 0, POPSIFT_HIP_GAUSS_VLFEAT_RELATIVE =
 enum { POPSIFT_HIP_DESC_LOOP = 0, POPSIFT_HIP_DESC_ILOOP = 1, POPSIFT_HIP_DESC_GRID = 2,
        POPSIFT_HIP_DESC_IGRID = 3, POPSIFT_HIP_DESC_NOTILE = 4 };
 enum { POPSIFT_HIP_NORM_ROOTSIFT = 0, POPSIFT_HIP_NORM_CLASSIC = 1 };
+/* Config::GridFilterMode (sift_conf.h:68-72): which extrema of an over-full cell survive */
+enum { POPSIFT_HIP_FILTER_RANDOM = 0, POPSIFT_HIP_FILTER_LARGEST_FIRST = 1, POPSIFT_HIP_FILTER_SMALLEST_FIRST = 2 };
 
 /* Flattened popsift::Config (sift_conf.h:28-310, defaults sift_conf.cu:17-39). */
 typedef struct popsift_hip_params {
@@ -63,8 +65,10 @@ typedef struct popsift_hip_params {
     int32_t max_extrema;         /* per octave, 100000                         */
     int32_t assume_initial_blur; /* 1                                          */
     float   initial_blur;        /* 0.5                                        */
-    int32_t filter_grid_size;    /* 2 (only feeds InitialExtremum::cell)       */
-    int32_t reserved[5];
+    int32_t filter_grid_size;    /* 2: the grid filter works on size x size cells */
+    int32_t filter_max_extrema;  /* -1 = grid filter off (s_orientation.cu:362)  */
+    int32_t filter_sorting;      /* POPSIFT_HIP_FILTER_*                         */
+    int32_t reserved[3];
 } popsift_hip_params;
 
 /* POD mirror of popsift::Feature (features.h:22-34): the four Descriptor*

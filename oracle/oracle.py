@@ -25,7 +25,8 @@ class Params(C.Structure):
         ("sift_mode", C.c_int32), ("gauss_mode", C.c_int32), ("desc_mode", C.c_int32),
         ("norm_mode", C.c_int32), ("norm_multi", C.c_int32), ("max_extrema", C.c_int32),
         ("assume_initial_blur", C.c_int32), ("initial_blur", C.c_float),
-        ("filter_grid_size", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("filter_grid_size", C.c_int32), ("filter_max_extrema", C.c_int32), ("filter_sorting", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -47,6 +48,8 @@ def default_params(**kw):
     p.assume_initial_blur = 1
     p.initial_blur = 0.5
     p.filter_grid_size = 2
+    p.filter_max_extrema = -1
+    p.filter_sorting = 0
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -104,6 +107,7 @@ def lib():
         L.oracle_fetch_raw_desc.argtypes = [vp, vp]
         L.oracle_solve3.argtypes = [vp, vp]
         L.oracle_normalize.argtypes = [vp, C.c_int, C.c_int]
+        L.oracle_filter_grid_keys.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -219,3 +223,13 @@ def normalize(d, norm_mode=0, norm_multi=0):
     d = np.array(d, np.float32).reshape(128).copy()
     lib().oracle_normalize(d.ctypes.data, norm_mode, norm_multi)
     return d
+
+
+def filter_grid_keys(cell, scale, grid_size, filter_max, mode):
+    """Grid filter on bare (cell, scale) keys; returns (keep mask, per-cell limit)."""
+    cell = np.ascontiguousarray(cell, np.int32)
+    scale = np.ascontiguousarray(scale, np.float32)
+    keep = np.zeros(len(cell), np.uint8)
+    lim = lib().oracle_filter_grid_keys(cell.ctypes.data, scale.ctypes.data, len(cell), grid_size, filter_max,
+                                        mode, keep.ctypes.data)
+    return keep.astype(bool), lim

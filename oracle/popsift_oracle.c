@@ -1155,12 +1155,151 @@ void oracle_normalize(float* d, int norm_mode, int norm_multi)
     }
 }
 
+/* ---------------------------------------------------------------- grid filter */
+
+/*
+ * Pyramid::extrema_filter_grid, s_filtergrid.cu:109-322 (hook: s_orientation.cu:362-367).
+ * Thins the initial extrema of ALL octaves to roughly filter_max_extrema by capping the number kept
+ * in each of the grid_size x grid_size image cells:
+ *   1. key every extremum by (cell, scale = sigma * 2^octave)           (:56-70)
+ *   2. order them by cell, inside a cell by scale descending / ascending, or -- RandomScale --
+ *      leave the cell's members in their original (octave, index) order    (:159-196)
+ *   3. counts of the NON-EMPTY cells in cell order, padded with zeros to n = grid_size^2 entries
+ *      (reduce_by_key compacts, the device_vector is zero-initialised)     (:199-202)
+ *   4. host arithmetic on the ascending-sorted counts c[0..n-1]: sumup[i] = c[i]*(n-1-i) + sum(c[0..i]);
+ *      ct = #{i : sumup[i] > max}; tailaverage = mean of the ct largest counts;
+ *      newlimit = ceil(tailaverage - (ext_total - max) / ct)  -- the quotient is an INTEGER division
+ *      (:247-256); every count is clamped to newlimit
+ *   5. in every cell the members beyond its clamped count are dropped       (:266-280)
+ *   6. the survivors keep their relative order inside their octave           (:286-314)
+ * Thrust's merge sort is stable, so members of a cell with equal scale stay in original order; the
+ * same is stated here with an index tie-break.  The original order itself is atomicAdd arrival order in
+ * the reference and raster order here, so RandomScale agrees with the reference only in the NUMBER
+ * kept per cell, not in the members.
+ */
+typedef struct {
+    int   cell;
+    float scale;
+    int   idx;
+} fkey_t;
+
+static int g_filter_mode; /* comparator context (the oracle filters one context at a time) */
+
+static int fkey_cmp(const void* a, const void* b)
+{
+    const fkey_t* l = (const fkey_t*)a;
+    const fkey_t* r = (const fkey_t*)b;
+    if (l->cell != r->cell) return l->cell < r->cell ? -1 : 1;
+    if (g_filter_mode == POPSIFT_HIP_FILTER_LARGEST_FIRST && l->scale != r->scale) return l->scale > r->scale ? -1 : 1;
+    if (g_filter_mode == POPSIFT_HIP_FILTER_SMALLEST_FIRST && l->scale != r->scale) return l->scale < r->scale ? -1 : 1;
+    return l->idx < r->idx ? -1 : (l->idx > r->idx ? 1 : 0);
+}
+
+static int int_cmp(const void* a, const void* b)
+{
+    const int l = *(const int*)a, r = *(const int*)b;
+    return l < r ? -1 : (l > r ? 1 : 0);
+}
+
+/* keep[i] = 1 if extremum i survives.  Returns the per-cell limit ("newlimit"), or -1 on error. */
+int oracle_filter_grid_keys(const int* cell, const float* scale, int n_ext, int grid_size, int filter_max,
+                            int mode, unsigned char* keep)
+{
+    const int n = grid_size * grid_size;
+    if (n_ext <= 0 || n <= 0) return -1;
+    fkey_t* k = (fkey_t*)malloc(sizeof(fkey_t) * (size_t)n_ext);
+    int*    counts = (int*)calloc((size_t)(n > n_ext ? n : n_ext) + 1, sizeof(int));
+    int*    start = (int*)calloc((size_t)n_ext + 1, sizeof(int));
+    int*    sorted = (int*)calloc((size_t)n, sizeof(int));
+    if (!k || !counts || !start || !sorted) return -1;
+    for (int i = 0; i < n_ext; i++) {
+        k[i].cell = cell[i];
+        k[i].scale = scale[i];
+        k[i].idx = i;
+    }
+    g_filter_mode = mode;
+    qsort(k, (size_t)n_ext, sizeof(fkey_t), fkey_cmp);
+
+    /* run lengths of equal cell values, in order (reduce_by_key) */
+    int groups = 0;
+    for (int i = 0; i < n_ext; i++) {
+        if (i == 0 || k[i].cell != k[i - 1].cell) {
+            start[groups] = i;
+            counts[groups++] = 0;
+        }
+        counts[groups - 1]++;
+    }
+    start[groups] = n_ext;
+    /* the reference's count vector has exactly n entries; more distinct cell values than that would
+     * overrun it there -- they cannot occur for positions inside the image */
+    for (int i = 0; i < n; i++) sorted[i] = i < groups ? counts[i] : 0;
+    qsort(sorted, (size_t)n, sizeof(int), int_cmp);
+
+    int ct = 0, prefix = 0;
+    for (int i = 0; i < n; i++) {
+        prefix += sorted[i];
+        const int sumup = sorted[i] * (n - 1 - i) + prefix;
+        if (sumup > filter_max) ct++;
+    }
+    int newlimit;
+    if (ct == 0) {
+        newlimit = 0x7fffffff; /* cannot happen when the caller's 10 % test passed; keep everything */
+    } else {
+        int tail = 0;
+        for (int i = n - ct; i < n; i++) tail += sorted[i];
+        const float tailaverage = (float)tail / ct;
+        newlimit = (int)ceilf(tailaverage - (float)((n_ext - filter_max) / ct));
+    }
+    memset(keep, 0, (size_t)n_ext);
+    for (int g = 0; g < groups; g++) {
+        const int kept = counts[g] < newlimit ? counts[g] : newlimit;
+        for (int j = 0; j < kept; j++) keep[k[start[g] + j].idx] = 1;
+    }
+    free(k);
+    free(counts);
+    free(start);
+    free(sorted);
+    return newlimit;
+}
+
+/* the hook of Pyramid::orientation, s_orientation.cu:353-367 */
+static int filter_grid(oracle_ctx* c)
+{
+    const int fmax = c->p.filter_max_extrema;
+    const int n = c->ext_total;
+    if (!(fmax > 0 && (int)(fmax * 1.1) < n)) return 0;
+    int*           cell = (int*)malloc(sizeof(int) * (size_t)n);
+    float*         scale = (float*)malloc(sizeof(float) * (size_t)n);
+    unsigned char* keep = (unsigned char*)malloc((size_t)n);
+    if (!cell || !scale || !keep) return -1;
+    for (int i = 0; i < n; i++) {
+        cell[i] = c->ext[i].cell;
+        scale[i] = c->ext[i].sigma * powf(2.0f, (float)c->ext[i].octave); /* s_filtergrid.cu:68 */
+    }
+    const int lim = oracle_filter_grid_keys(cell, scale, n, c->p.filter_grid_size, fmax, c->p.filter_sorting, keep);
+    if (lim < 0) return -1;
+    int out = 0;
+    for (int o = 0; o < MAXO; o++) c->ext_ct[o] = 0;
+    for (int i = 0; i < n; i++) {
+        if (keep[i]) {
+            c->ext_ct[c->ext[i].octave]++;
+            c->ext[out++] = c->ext[i];
+        }
+    }
+    c->ext_total = out;
+    free(cell);
+    free(scale);
+    free(keep);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ driver */
 
 static int keypoint_stages(oracle_ctx* c)
 {
     if (c->n_oct <= 0) return -1;
     if (find_extrema(c)) return -1;
+    if (filter_grid(c)) return -1;
     const int n = c->ext_total;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(c->threads) if (c->threads > 1)
     for (int i = 0; i < n; i++) orientation_one(c, &c->ext[i]);

@@ -33,7 +33,8 @@ class Params(C.Structure):
         ("sift_mode", C.c_int32), ("gauss_mode", C.c_int32), ("desc_mode", C.c_int32),
         ("norm_mode", C.c_int32), ("norm_multi", C.c_int32), ("max_extrema", C.c_int32),
         ("assume_initial_blur", C.c_int32), ("initial_blur", C.c_float),
-        ("filter_grid_size", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("filter_grid_size", C.c_int32), ("filter_max_extrema", C.c_int32), ("filter_sorting", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

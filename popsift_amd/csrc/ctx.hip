@@ -70,6 +70,9 @@ struct popsift_hip_ctx {
     size_t  arena_cap = 0; /* floats */
     PyrDesc pd{};
     InitExt* d_iext = nullptr;
+    InitExt* d_iext2 = nullptr;      /* grid filter output (filter enabled only) */
+    FilterState* d_fstate = nullptr;
+    int*     d_fhist = nullptr;
     Ext*     d_ext = nullptr;
     popsift_hip_feature* d_feats = nullptr;
     size_t   ext_cap = 0; /* entries in d_iext/d_ext/d_feats */
@@ -172,6 +175,8 @@ void init_tables(popsift_hip_ctx* c)
     sc.grid_size = p.filter_grid_size > 0 ? p.filter_grid_size : 1;
     sc.up_fac_int = (int)p.upscale_factor;
     sc.desc_mode = p.desc_mode;
+    sc.filter_max = p.filter_max_extrema;
+    sc.filter_mode = p.filter_sorting;
     {
         const char* e = getenv("POPSIFT_HIP_DET_QCAP"); /* test hook: force strips into the slow detection pass */
         sc.det_qcap = e ? std::max(atoi(e), 0) : (1 << 30);
@@ -274,8 +279,14 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
         if (int rc = grow(c, &c->d_iext, &cap0, need_ext)) return rc;
         if (int rc = grow(c, &c->d_ext, &cap1, need_ext)) return rc;
         if (int rc = grow(c, &c->d_feats, &cap2, need_ext)) return rc;
+        if (c->sc.filter_max > 0) {
+            size_t cap3 = c->ext_cap;
+            if (int rc = grow(c, &c->d_iext2, &cap3, need_ext)) return rc;
+        }
         c->ext_cap = need_ext;
     }
+    if (c->sc.filter_max > 0 && !filter_supported(n_oct, c->sc.max_extrema, c->sc.grid_size))
+        return fail(c, POPSIFT_HIP_ERR_INVALID, "grid filter: grid size > 64 or octaves * max_extrema >= 2^25");
     if (int rc = grow(c, &c->d_partial, &c->partial_cap, need_ext / scan_chunk() + 2)) return rc;
     /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
@@ -371,12 +382,18 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 }
 
 /* Pyramid::step2 + prep_features: extrema -> orientation -> scan -> descriptors -> features */
+InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iext2 : c->d_iext; }
+
 int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
     HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_ovf, c->d_iext,
                               c->stream));
-    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_iext, c->d_ext, 8192, c->stream));
+    if (c->sc.filter_max > 0) {
+        /* Pyramid::orientation's filter hook (s_orientation.cu:353-367); the 10 % test is taken on the device */
+        HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->d_ct, c->d_iext, c->d_iext2, c->d_fstate, c->d_fhist, c->stream));
+    }
+    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ext, 8192, c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->desc_cap,
                            c->stream));
@@ -534,6 +551,8 @@ void popsift_hip_default_params(popsift_hip_params* p)
     p->assume_initial_blur = 1;
     p->initial_blur = 0.5f;
     p->filter_grid_size = 2;
+    p->filter_max_extrema = -1;
+    p->filter_sorting = POPSIFT_HIP_FILTER_RANDOM;
 }
 
 const char* popsift_hip_version(void) { return "popsift_hip 0.1 (gfx950, wave64)"; }
@@ -580,6 +599,9 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
         return POPSIFT_HIP_ERR_INVALID;
     if (p->sift_mode < 0 || p->sift_mode > 2 || p->norm_mode < 0 || p->norm_mode > 1) return POPSIFT_HIP_ERR_INVALID;
     if (p->max_extrema < 1 || !(p->edge_limit > 0.0f)) return POPSIFT_HIP_ERR_INVALID;
+    if (p->filter_max_extrema > 0 &&
+        (p->filter_grid_size < 1 || p->filter_grid_size > 64 || p->filter_sorting < 0 || p->filter_sorting > 2))
+        return POPSIFT_HIP_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return POPSIFT_HIP_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return POPSIFT_HIP_ERR_INVALID;
@@ -602,6 +624,10 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
         HIP_TRY(c, hipHostMalloc((void**)&c->h_pd, sizeof(PyrDesc), hipHostMallocDefault));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_ct, sizeof(Counters), hipHostMallocDefault));
         memset(c->h_ct, 0, sizeof(Counters));
+        if (p->filter_max_extrema > 0) {
+            HIP_TRY(c, hipMalloc((void**)&c->d_fstate, sizeof(FilterState)));
+            HIP_TRY(c, hipMalloc((void**)&c->d_fhist, filter_hist_bytes(c->sc.grid_size)));
+        }
         return 0;
     }();
     if (rc) {
@@ -627,6 +653,9 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->h_input) (void)hipHostFree(c->h_input);
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_iext) (void)hipFree(c->d_iext);
+    if (c->d_iext2) (void)hipFree(c->d_iext2);
+    if (c->d_fstate) (void)hipFree(c->d_fstate);
+    if (c->d_fhist) (void)hipFree(c->d_fhist);
     if (c->d_ext) (void)hipFree(c->d_ext);
     if (c->d_feats) (void)hipFree(c->d_feats);
     if (c->d_map) (void)hipFree(c->d_map);
@@ -777,7 +806,7 @@ int popsift_hip_download_extrema(popsift_hip_ctx* c, popsift_hip_extremum* out, 
     for (int o = 0; o < c->pd.n_oct; o++) {
         const int cnt = c->rep.ext_ct[o];
         if (cnt <= 0) continue;
-        HIP_TRY(c, hipMemcpy(tmp.data(), c->d_iext + (size_t)o * c->sc.max_extrema, (size_t)cnt * sizeof(InitExt),
+        HIP_TRY(c, hipMemcpy(tmp.data(), final_iext(c) + (size_t)o * c->sc.max_extrema, (size_t)cnt * sizeof(InitExt),
                              hipMemcpyDeviceToHost));
         for (int i = 0; i < cnt; i++, k++) {
             out[k].xpos = tmp[i].xpos;

@@ -44,4 +44,10 @@ hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const Sif
 hipError_t launch_prep(const SiftConsts& sc, const Counters* ct, const Ext* ext, popsift_hip_feature* feats,
                        int desc_cap, int blocks, hipStream_t s);
 
+/* filter.hip: grid filter between refinement and orientation (s_filtergrid.cu:109-322) */
+bool       filter_supported(int n_oct, int max_extrema, int grid_size);
+size_t     filter_hist_bytes(int grid_size);
+hipError_t launch_filter(int n_oct, const SiftConsts& sc, Counters* ct, const InitExt* iext, InitExt* iext_out,
+                         FilterState* fs, int* hist, hipStream_t s);
+
 }  // namespace popsift_hip

@@ -42,6 +42,8 @@ struct SiftConsts {
     int   up_fac_int; /* prep_features(Descriptor*, int up_fac): truncated, sift_pyramid.cu:250 */
     int   desc_mode;  /* POPSIFT_HIP_DESC_LOOP or _GRID */
     int   det_qcap;   /* candidate queue entries the fast detection pass may use (tests shrink it) */
+    int   filter_max;  /* Config::getFilterMaxExtrema(), <= 0: grid filter off */
+    int   filter_mode; /* POPSIFT_HIP_FILTER_* */
 };
 
 /* sift_extremum.h:24-33 InitialExtremum (without the grid-filter bookkeeping) */
@@ -72,4 +74,18 @@ struct Counters {
     int ext_total;
     int ori_total;
     int pad[2]; /* [0] candidates found by the detection kernel, [1] strips left to its slow pass */
+};
+
+/* grid filter working set (filter.hip), device resident */
+#define FILTER_MAX_CELLS 4096 /* grid_size <= 64 */
+struct FilterState {
+    int                active;   /* the reference's 10 % test passed: the filter really thins */
+    int                newlimit; /* per-cell cap derived from the counts */
+    int                pad[2];
+    int                new_ct[PS_MAX_OCT];
+    int                cell_count[FILTER_MAX_CELLS];
+    int                cell_limit[FILTER_MAX_CELLS];
+    int                remaining[FILTER_MAX_CELLS]; /* radix select: members still to cover */
+    int                cell_mode[FILTER_MAX_CELLS]; /* 0 select, 1 keep all, 2 keep none */
+    unsigned long long prefix[FILTER_MAX_CELLS];    /* radix select: digits chosen so far */
 };

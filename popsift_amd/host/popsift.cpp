@@ -52,6 +52,8 @@ popsift_hip_params to_params(const popsift::Config& c)
     p.assume_initial_blur = c.hasInitialBlur() ? 1 : 0;
     p.initial_blur = c.getInitialBlur();
     p.filter_grid_size = c.getFilterGridSize();
+    p.filter_max_extrema = c.getFilterMaxExtrema();
+    p.filter_sorting = (int)c.getFilterSorting(); /* RandomScale, LargestScaleFirst, SmallestScaleFirst */
     return p;
 }
 
@@ -146,6 +148,8 @@ bool PopSift::configure(const popsift::Config& config, bool /*force*/)
         _config.getDescMode() != popsift::Config::NoTile)
         DIE("this build implements the descriptor modes 'loop', 'grid' and 'notile' only");
     if (_config.getScalingMode() != popsift::Config::ScaleDefault) DIE("ScaleDirect is not supported");
+    if (_config.getFilterMaxExtrema() > 0 && (_config.getFilterGridSize() < 1 || _config.getFilterGridSize() > 64))
+        DIE("the grid filter supports grid sizes 1..64");
     _shadow_config = _config;
     return true;
 }

@@ -126,6 +126,24 @@ const char* popsift_hip_last_error(const popsift_hip_ctx* ctx);
 /* Replaces common/device_prop.cu:23-47 (device enumeration). */
 int popsift_hip_device_count(int* count);
 
+/* What device_prop_t::print shows (common/device_prop.cu:39-70), as a POD. */
+typedef struct popsift_hip_device_info {
+    char     name[256];
+    int32_t  arch_major, arch_minor; /* "compute capability" slot: gfx major / minor */
+    uint64_t total_mem;              /* bytes of HBM */
+    uint64_t lds_per_block;          /* "per-block shared mem" */
+    int32_t  wave_size;              /* 64 on CDNA */
+    int32_t  max_threads_per_block;
+    int32_t  max_threads_per_cu;
+    int32_t  max_block[3];
+    int32_t  max_grid[3];
+    int32_t  cu_count;               /* "number of SM(x)s" */
+    int32_t  concurrent_kernels;
+    int32_t  can_map_host;
+    int32_t  unified_addressing;
+} popsift_hip_device_info;
+int popsift_hip_get_device_info(int device, popsift_hip_device_info* out);
+
 /* Replaces PopSift::configure (popsift.cpp:63-87: init_filter + init_constants)
  * and Pyramid::Pyramid (sift_pyramid.cu:108-165); buffers are sized lazily on
  * the first image and only grow (contrast sift_octave.cu:55-89). */

@@ -50,6 +50,17 @@ class Report(C.Structure):
     ]
 
 
+class DeviceInfo(C.Structure):
+    """popsift_hip_device_info"""
+    _fields_ = [
+        ("name", C.c_char * 256), ("arch_major", C.c_int32), ("arch_minor", C.c_int32),
+        ("total_mem", C.c_uint64), ("lds_per_block", C.c_uint64), ("wave_size", C.c_int32),
+        ("max_threads_per_block", C.c_int32), ("max_threads_per_cu", C.c_int32),
+        ("max_block", C.c_int32 * 3), ("max_grid", C.c_int32 * 3), ("cu_count", C.c_int32),
+        ("concurrent_kernels", C.c_int32), ("can_map_host", C.c_int32), ("unified_addressing", C.c_int32),
+    ]
+
+
 FEATURE_DTYPE = np.dtype([
     ("debug_octave", np.int32), ("xpos", np.float32), ("ypos", np.float32),
     ("sigma", np.float32), ("num_ori", np.int32),
@@ -68,6 +79,7 @@ SYMBOLS = [
     ("popsift_hip_strerror", C.c_char_p, [C.c_int]),
     ("popsift_hip_last_error", C.c_char_p, [_vp]),
     ("popsift_hip_device_count", C.c_int, [_ip]),
+    ("popsift_hip_get_device_info", C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),
     ("popsift_hip_ctx_create", C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(_vp)]),
     ("popsift_hip_ctx_destroy", C.c_int, [_vp]),
     ("popsift_hip_get_gauss_table", C.c_int, [_vp, _vp, _vp, _vp, _ip]),
@@ -132,6 +144,14 @@ def device_count():
     n = C.c_int(0)
     rc = lib().popsift_hip_device_count(C.byref(n))
     return n.value if rc == OK else 0
+
+
+def device_info(device=0):
+    d = DeviceInfo()
+    rc = lib().popsift_hip_get_device_info(device, C.byref(d))
+    if rc != OK:
+        raise PopsiftHipError(rc, "popsift_hip_get_device_info")
+    return d
 
 
 class Context:

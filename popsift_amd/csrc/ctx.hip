@@ -585,6 +585,34 @@ int popsift_hip_device_count(int* count)
     return n > 0 ? POPSIFT_HIP_OK : POPSIFT_HIP_ERR_NO_DEVICE;
 }
 
+int popsift_hip_get_device_info(int device, popsift_hip_device_info* out)
+{
+    if (!out) return POPSIFT_HIP_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return POPSIFT_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return POPSIFT_HIP_ERR_INVALID;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return POPSIFT_HIP_ERR_DEVICE;
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s (%s)", pr.name, pr.gcnArchName);
+    out->arch_major = pr.major;
+    out->arch_minor = pr.minor;
+    out->total_mem = pr.totalGlobalMem;
+    out->lds_per_block = pr.sharedMemPerBlock;
+    out->wave_size = pr.warpSize;
+    out->max_threads_per_block = pr.maxThreadsPerBlock;
+    out->max_threads_per_cu = pr.maxThreadsPerMultiProcessor;
+    for (int i = 0; i < 3; i++) {
+        out->max_block[i] = pr.maxThreadsDim[i];
+        out->max_grid[i] = pr.maxGridSize[i];
+    }
+    out->cu_count = pr.multiProcessorCount;
+    out->concurrent_kernels = pr.concurrentKernels;
+    out->can_map_host = pr.canMapHostMemory;
+    out->unified_addressing = 1; /* HIP on ROCm: one virtual address space for host and device */
+    return POPSIFT_HIP_OK;
+}
+
 int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_ctx** out)
 {
     if (!p || !out) return POPSIFT_HIP_ERR_INVALID;

@@ -19,6 +19,8 @@
 #include <iostream>
 #include <sstream>
 
+#include "debug_dump.h"
+#include "popsift/common/device_prop.h"
 #include "popsift_hip.h"
 
 using namespace std;
@@ -63,6 +65,14 @@ std::vector<int> device_list()
     if (popsift_hip_device_count(&n) != POPSIFT_HIP_OK || n <= 0) DIE("no usable GPU found");
     std::vector<int> devs;
     const char*      e = getenv("POPSIFT_DEVICES");
+    if (!e || !*e) {
+        /* device_prop_t::set(n) plays cudaSetDevice(n) (main.cpp:300-302): that GPU only */
+        const int chosen = popsift::cuda::device_prop_t::chosenDevice();
+        if (chosen >= 0 && chosen < n) {
+            devs.push_back(chosen);
+            return devs;
+        }
+    }
     if (!e || !*e || string(e) == "all") {
         for (int i = 0; i < n; i++) devs.push_back(i);
         return devs;
@@ -220,6 +230,14 @@ void PopSift::worker_loop(Worker* me)
                     f.desc[k] = s.desc_idx[k] >= 0 ? base + s.desc_idx[k] : 0;
                 }
             }
+        }
+        if (_config.getLogMode() == popsift::Config::All) {
+            /* popsift.cpp:201-209; with several workers the dumps of concurrent images overwrite
+             * each other exactly as successive images do in the reference */
+            static std::mutex           dump_mtx;
+            std::lock_guard<std::mutex> lk(dump_mtx);
+            popsift::debug::download_and_save_array(me->ctx, _config, "pyramid");
+            popsift::debug::save_descriptors(_config, features, "pyramid");
         }
         job->setFeatures(features);
     }

@@ -2,8 +2,8 @@
  * popsift/features.h -- result containers of the drop-in API.
  * Replaces features.h:22-96 (Feature, FeaturesBase, FeaturesHost, typedef Features).
  * Layouts are the reference's: Feature keeps its four Descriptor* which point
- * into the FeaturesHost's own descriptor array.  FeaturesDev (device-resident
- * results + brute-force matcher, features.h:98-118) is not part of this build.
+ * into the FeaturesHost's own descriptor array.  FeaturesDev (features.h:98-118)
+ * holds the results of an image in GPU memory and matches two such sets.
  */
 #pragma once
 
@@ -12,6 +12,8 @@
 
 #include "sift_constants.h"
 #include "sift_extremum.h"
+
+struct popsift_hip_devfeatures;
 
 namespace popsift {
 
@@ -80,10 +82,42 @@ typedef FeaturesHost Features;
 
 std::ostream& operator<<(std::ostream& ostr, const FeaturesHost& feature);
 
-/* MatchingMode is not part of this build; the type exists so that code mentioning it compiles */
+/*
+ * Device-resident results of one image (PopSift in Config::MatchingMode, SiftJob::getDev()).
+ * The three arrays live in the memory of the GPU that extracted the image: Feature records whose
+ * desc[] point into the descriptor array, the descriptors, and the descriptor -> feature map.
+ */
 class FeaturesDev : public FeaturesBase {
+    popsift_hip_devfeatures* _set;
+
 public:
-    FeaturesDev() {}
+    FeaturesDev();
+    FeaturesDev(int num_ext, int num_ori);
+    /* takes ownership of a set made by the C ABI (popsift_hip_clone_results) */
+    explicit FeaturesDev(popsift_hip_devfeatures* adopt);
+    virtual ~FeaturesDev();
+
+    void reset(int num_ext, int num_ori);
+
+    /* brute-force 2-nearest-neighbour search of every descriptor of this set among the descriptors of
+     * `other`; prints one "accept ..." / "reject ..." line per descriptor on stdout, as the reference does */
+    void match(FeaturesDev* other);
+
+    /* extension: the same search, results returned instead of printed */
+    struct Match {
+        int   best, second; /* descriptor indices in `other` */
+        bool  accept;       /* dist_best / dist_second < 0.8 */
+        float dist_best, dist_second; /* squared L2 */
+    };
+    std::vector<Match> matchAndGet(FeaturesDev* other);
+
+    /* DEVICE pointers */
+    Feature*    getFeatures();
+    Descriptor* getDescriptors();
+    int*        getReverseMap();
+
+    int                      getDevice() const;
+    popsift_hip_devfeatures* getHandle() { return _set; }
 };
 
 }  // namespace popsift

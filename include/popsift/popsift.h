@@ -118,4 +118,5 @@ private:
     int             _last_init_w = 0;
     int             _last_init_h = 0;
     ImageMode       _image_mode;
+    popsift::Config::ProcessingMode _proc_mode = popsift::Config::ExtractingMode;
 };

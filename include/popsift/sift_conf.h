@@ -44,7 +44,7 @@ struct Config {
     enum GridFilterMode { RandomScale, LargestScaleFirst, SmallestScaleFirst };
 
     /* ExtractingMode: features are downloaded to the host (FeaturesHost).
-     * MatchingMode (device-resident FeaturesDev + matcher) is not part of this build. */
+     * MatchingMode: features stay on the GPU (FeaturesDev, SiftJob::getDev()) for FeaturesDev::match. */
     enum ProcessingMode { ExtractingMode, MatchingMode };
 
     /* ---- setters (sift_conf.cu:51-258) -------------------------------------- */

@@ -184,6 +184,38 @@ int popsift_hip_results_dev(popsift_hip_ctx* ctx, const void** d_feats, const vo
 void* popsift_hip_host_alloc(size_t bytes);
 void  popsift_hip_host_free(void* p);
 
+/* ---- MatchingMode ------------------------------------------------------------
+ * Device-resident copy of the last image's results: replaces Pyramid::clone_device_descriptors
+ * (sift_pyramid.cu:323-361) and FeaturesDev (features.h:98-118).  The set lives on the context's
+ * GPU and is independent of the context afterwards. */
+typedef struct popsift_hip_devfeatures popsift_hip_devfeatures;
+int popsift_hip_clone_results(popsift_hip_ctx* ctx, popsift_hip_devfeatures** out);
+int popsift_hip_devfeatures_free(popsift_hip_devfeatures* f);
+int popsift_hip_devfeatures_info(const popsift_hip_devfeatures* f, int* device, int* n_features, int* n_descriptors);
+/* Device pointers: features in the 72-byte layout of popsift::Feature (features.h:22-34) whose
+ * desc[] point into the descriptor array, descriptors (128 floats each), descriptor -> feature map. */
+int popsift_hip_devfeatures_ptrs(const popsift_hip_devfeatures* f, void** d_features, void** d_descriptors,
+                                 void** d_reverse_map);
+/* An empty (zero-filled) set of the given sizes: FeaturesDev::reset (features.cu:148-160). */
+int popsift_hip_devfeatures_alloc(int device, int n_features, int n_descriptors, popsift_hip_devfeatures** out);
+/* A set from caller-supplied HOST descriptors (n * 128 floats), for matching without extraction. */
+int popsift_hip_devfeatures_from_host(int device, const float* desc, int n_descriptors, popsift_hip_devfeatures** out);
+/* Host copies (tests, printing): desc n_descriptors*128 floats, rev n_descriptors ints; either may be NULL. */
+int popsift_hip_devfeatures_download(const popsift_hip_devfeatures* f, float* desc, int32_t* rev);
+
+/* One row of the reference's match_matrix (int3, features.cu:178-220) plus the two squared distances. */
+typedef struct popsift_hip_match {
+    int32_t best;        /* index of the nearest right descriptor        */
+    int32_t second;      /* index of the second nearest                  */
+    int32_t accept;      /* dist_best / dist_second < 0.8                */
+    float   dist_best;   /* squared L2 distances                         */
+    float   dist_second;
+} popsift_hip_match;
+/* Replaces FeaturesDev::match / compute_distance (features.cu:157-300): brute-force 2-NN of every
+ * descriptor of `l` among the descriptors of `r`; out has l's descriptor count entries (host memory).
+ * Sets on different GPUs are allowed (the right set is copied to the left set's GPU). */
+int popsift_hip_match_sets(const popsift_hip_devfeatures* l, const popsift_hip_devfeatures* r, popsift_hip_match* out);
+
 int popsift_hip_get_report(const popsift_hip_ctx* ctx, popsift_hip_report* rep);
 /* profile != 0: bracket every blur-level launch with HIP events (serialises the
  * octave streams; used by bench.py for the roofline object only). */

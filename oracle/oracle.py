@@ -107,6 +107,8 @@ def lib():
         L.oracle_fetch_raw_desc.argtypes = [vp, vp]
         L.oracle_solve3.argtypes = [vp, vp]
         L.oracle_normalize.argtypes = [vp, C.c_int, C.c_int]
+        L.oracle_match.restype = None
+        L.oracle_match.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
         L.oracle_filter_grid_keys.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         _lib = L
     return _lib
@@ -233,3 +235,16 @@ def filter_grid_keys(cell, scale, grid_size, filter_max, mode):
     lim = lib().oracle_filter_grid_keys(cell.ctypes.data, scale.ctypes.data, len(cell), grid_size, filter_max,
                                         mode, keep.ctypes.data)
     return keep.astype(bool), lim
+
+
+MATCH_DTYPE = np.dtype([("best", np.int32), ("second", np.int32), ("accept", np.int32),
+                        ("dist_best", np.float32), ("dist_second", np.float32)])
+
+
+def match(l, r, threads=8):
+    """Brute-force 2-NN (FeaturesDev::match, features.cu:157-221) of l's rows among r's rows."""
+    l = np.ascontiguousarray(l, np.float32).reshape(-1, 128)
+    r = np.ascontiguousarray(r, np.float32).reshape(-1, 128)
+    out = np.zeros(len(l), MATCH_DTYPE)
+    lib().oracle_match(l.ctypes.data, len(l), r.ctypes.data, len(r), out.ctypes.data, threads)
+    return out

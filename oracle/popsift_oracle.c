@@ -1293,6 +1293,51 @@ static int filter_grid(oracle_ctx* c)
     return 0;
 }
 
+/* ------------------------------------------------------------------- matching */
+
+/* l2_in_t0, features.cu:157-176: lane t of a 32-thread block squares and sums float4 number t of the
+ * difference (nvcc contracts x*x + y*y + z*z + w*w into an FMA chain), then shuffle_down(16,8,4,2,1)
+ * adds the 32 lane values; lane 0 holds the result. */
+static float l2_in_t0(const float* l, const float* r)
+{
+    float lane[32];
+    for (int t = 0; t < 32; t++) {
+        const float x = l[4 * t] - r[4 * t], y = l[4 * t + 1] - r[4 * t + 1];
+        const float z = l[4 * t + 2] - r[4 * t + 2], w = l[4 * t + 3] - r[4 * t + 3];
+        lane[t] = fmaf(w, w, fmaf(z, z, fmaf(y, y, x * x)));
+    }
+    for (int s = 16; s >= 1; s >>= 1)
+        for (int t = 0; t < s; t++) lane[t] = lane[t] + lane[t + s]; /* only the lanes that reach lane 0 */
+    return lane[0];
+}
+
+/* compute_distance, features.cu:177-221: out[i] = {best, second, accept, d_best, d_second} */
+void oracle_match(const float* l, int l_len, const float* r, int r_len, popsift_hip_match* out, int threads)
+{
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads < 1 ? 1 : threads) if (threads > 1)
+    for (int idx = 0; idx < l_len; idx++) {
+        float match_1st_val = INFINITY, match_2nd_val = INFINITY;
+        int   match_1st_idx = 0, match_2nd_idx = 0;
+        for (int i = 0; i < r_len; i++) {
+            const float res = l2_in_t0(l + 128 * (size_t)idx, r + 128 * (size_t)i);
+            if (res < match_1st_val) {
+                match_2nd_val = match_1st_val;
+                match_2nd_idx = match_1st_idx;
+                match_1st_val = res;
+                match_1st_idx = i;
+            } else if (res < match_2nd_val) {
+                match_2nd_val = res;
+                match_2nd_idx = i;
+            }
+        }
+        out[idx].best = match_1st_idx;
+        out[idx].second = match_2nd_idx;
+        out[idx].accept = (match_1st_val / match_2nd_val < 0.8f) ? 1 : 0;
+        out[idx].dist_best = match_1st_val;
+        out[idx].dist_second = match_2nd_val;
+    }
+}
+
 /* ------------------------------------------------------------------ driver */
 
 static int keypoint_stages(oracle_ctx* c)

@@ -56,6 +56,8 @@ int oracle_fetch_raw_desc(const oracle_ctx* c, float* desc);
 /* isolated helpers for unit tests */
 int   oracle_solve3(float A[9], float b[3]);                 /* s_solve.h:24-85 */
 void  oracle_normalize(float* d128, int norm_mode, int norm_multi); /* s_desc_norm_*.h */
+/* brute-force 2-NN of every left descriptor among the right ones (features.cu:157-221) */
+void  oracle_match(const float* l, int l_len, const float* r, int r_len, popsift_hip_match* out, int threads);
 /* grid filter on bare keys (s_filtergrid.cu:109-322): keep[i] = 1 for survivors; returns the per-cell limit */
 int   oracle_filter_grid_keys(const int* cell, const float* scale, int n_ext, int grid_size, int filter_max,
                               int mode, unsigned char* keep);

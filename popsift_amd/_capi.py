@@ -66,6 +66,8 @@ FEATURE_DTYPE = np.dtype([
     ("sigma", np.float32), ("num_ori", np.int32),
     ("orientation", np.float32, (ORI_MAX,)), ("desc_idx", np.int32, (ORI_MAX,)),
 ])
+MATCH_DTYPE = np.dtype([("best", np.int32), ("second", np.int32), ("accept", np.int32),
+                        ("dist_best", np.float32), ("dist_second", np.float32)])
 EXTREMUM_DTYPE = np.dtype([
     ("xpos", np.float32), ("ypos", np.float32), ("lpos", np.int32),
     ("sigma", np.float32), ("octave", np.int32), ("cell", np.int32),
@@ -92,6 +94,14 @@ SYMBOLS = [
     ("popsift_hip_results_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     ("popsift_hip_host_alloc", _vp, [C.c_size_t]),
     ("popsift_hip_host_free", None, [_vp]),
+    ("popsift_hip_clone_results", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("popsift_hip_devfeatures_free", C.c_int, [_vp]),
+    ("popsift_hip_devfeatures_info", C.c_int, [_vp, _ip, _ip, _ip]),
+    ("popsift_hip_devfeatures_ptrs", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    ("popsift_hip_devfeatures_alloc", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("popsift_hip_devfeatures_from_host", C.c_int, [C.c_int, _vp, C.c_int, C.POINTER(_vp)]),
+    ("popsift_hip_devfeatures_download", C.c_int, [_vp, _vp, _vp]),
+    ("popsift_hip_match_sets", C.c_int, [_vp, _vp, _vp]),
     ("popsift_hip_get_report", C.c_int, [_vp, C.POINTER(Report)]),
     ("popsift_hip_set_profile", C.c_int, [_vp, C.c_int]),
     ("popsift_hip_octave_dims", C.c_int, [_vp, C.c_int, _ip, _ip]),
@@ -152,6 +162,55 @@ def device_info(device=0):
     if rc != OK:
         raise PopsiftHipError(rc, "popsift_hip_get_device_info")
     return d
+
+
+class DevFeatures:
+    """popsift_hip_devfeatures: a device-resident result set (FeaturesDev, features.h:98-118)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_host(cls, desc, device=0):
+        desc = np.ascontiguousarray(desc, np.float32).reshape(-1, 128)
+        h = _vp()
+        rc = lib().popsift_hip_devfeatures_from_host(device, desc.ctypes.data, len(desc), C.byref(h))
+        if rc != OK:
+            raise PopsiftHipError(rc, "popsift_hip_devfeatures_from_host")
+        return cls(h)
+
+    def info(self):
+        d, nf, nd = C.c_int(), C.c_int(), C.c_int()
+        lib().popsift_hip_devfeatures_info(self._h, C.byref(d), C.byref(nf), C.byref(nd))
+        return d.value, nf.value, nd.value
+
+    def download(self):
+        _, _, nd = self.info()
+        desc = np.zeros((nd, 128), np.float32)
+        rev = np.zeros(nd, np.int32)
+        rc = lib().popsift_hip_devfeatures_download(self._h, desc.ctypes.data, rev.ctypes.data)
+        if rc != OK:
+            raise PopsiftHipError(rc, "popsift_hip_devfeatures_download")
+        return desc, rev
+
+    def match(self, other):
+        _, _, nd = self.info()
+        out = np.zeros(nd, MATCH_DTYPE)
+        rc = lib().popsift_hip_match_sets(self._h, other._h, out.ctypes.data)
+        if rc != OK:
+            raise PopsiftHipError(rc, "popsift_hip_match_sets")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().popsift_hip_devfeatures_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -256,6 +315,11 @@ class Context:
         self._chk(lib().popsift_hip_download_extrema(self._h, out.ctypes.data, n.value, C.byref(n)),
                   "download_extrema")
         return out
+
+    def clone_results(self):
+        h = _vp()
+        self._chk(lib().popsift_hip_clone_results(self._h, C.byref(h)), "popsift_hip_clone_results")
+        return DevFeatures(h)
 
     def rerun_keypoint_stages(self):
         self._chk(lib().popsift_hip_rerun_keypoint_stages(self._h), "rerun_keypoint_stages")

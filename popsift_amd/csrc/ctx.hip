@@ -23,6 +23,7 @@
 #include <new>
 #include <vector>
 
+#include "devfeatures.h"
 #include "kernels.h"
 #include "sift_types.h"
 
@@ -757,6 +758,189 @@ int popsift_hip_results_dev(popsift_hip_ctx* c, const void** d_feats, const void
     if (d_feats) *d_feats = c->d_feats;
     if (d_desc) *d_desc = c->d_desc;
     return POPSIFT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------ MatchingMode (N3) */
+
+int popsift_hip_clone_results(popsift_hip_ctx* c, popsift_hip_devfeatures** out)
+{
+    if (!c || !out) return POPSIFT_HIP_ERR_INVALID;
+    *out = nullptr;
+    if (int rc = finish(c)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    popsift_hip_devfeatures* f = new (std::nothrow) popsift_hip_devfeatures();
+    if (!f) return fail(c, POPSIFT_HIP_ERR_OOM, "out of host memory");
+    f->device = c->device;
+    f->n_feat = c->rep.ext_total;
+    f->n_desc = c->rep.ori_total;
+    int rc = [&]() -> int {
+        /* allocations of at least one element keep the pointers valid for empty results */
+        HIP_TRY(c, hipMalloc((void**)&f->d_feat, sizeof(DevFeature) * (size_t)std::max(f->n_feat, 1)));
+        HIP_TRY(c, hipMalloc((void**)&f->d_desc, sizeof(float) * 128 * (size_t)std::max(f->n_desc, 1)));
+        HIP_TRY(c, hipMalloc((void**)&f->d_rev, sizeof(int) * (size_t)std::max(f->n_desc, 1)));
+        /* sift_pyramid.cu:323-345: prep_features into the clone, then the two device-to-device copies */
+        HIP_TRY(c, launch_clone_features(c->d_feats, f->n_feat, f->d_desc, f->d_feat, c->stream));
+        if (f->n_desc > 0) {
+            HIP_TRY(c, hipMemcpyAsync(f->d_desc, c->d_desc, sizeof(float) * 128 * (size_t)f->n_desc,
+                                      hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(f->d_rev, c->d_map, sizeof(int) * (size_t)f->n_desc, hipMemcpyDeviceToDevice,
+                                      c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    if (rc) {
+        popsift_hip_devfeatures_free(f);
+        return rc;
+    }
+    *out = f;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_devfeatures_free(popsift_hip_devfeatures* f)
+{
+    if (!f) return POPSIFT_HIP_OK;
+    (void)hipSetDevice(f->device);
+    if (f->d_feat) (void)hipFree(f->d_feat);
+    if (f->d_desc) (void)hipFree(f->d_desc);
+    if (f->d_rev) (void)hipFree(f->d_rev);
+    if (f->m_stream) (void)hipStreamDestroy((hipStream_t)f->m_stream);
+    if (f->m_partial) (void)hipFree(f->m_partial);
+    if (f->m_out) (void)hipFree(f->m_out);
+    if (f->m_host) (void)hipHostFree(f->m_host);
+    delete f;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_devfeatures_info(const popsift_hip_devfeatures* f, int* device, int* n_features, int* n_descriptors)
+{
+    if (!f) return POPSIFT_HIP_ERR_INVALID;
+    if (device) *device = f->device;
+    if (n_features) *n_features = f->n_feat;
+    if (n_descriptors) *n_descriptors = f->n_desc;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_devfeatures_ptrs(const popsift_hip_devfeatures* f, void** d_features, void** d_descriptors,
+                                 void** d_reverse_map)
+{
+    if (!f) return POPSIFT_HIP_ERR_INVALID;
+    if (d_features) *d_features = f->d_feat;
+    if (d_descriptors) *d_descriptors = f->d_desc;
+    if (d_reverse_map) *d_reverse_map = f->d_rev;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_devfeatures_alloc(int device, int n_feat, int n_desc, popsift_hip_devfeatures** out)
+{
+    if (!out || n_feat < 0 || n_desc < 0) return POPSIFT_HIP_ERR_INVALID;
+    *out = nullptr;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return POPSIFT_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= nd) return POPSIFT_HIP_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return POPSIFT_HIP_ERR_DEVICE;
+    popsift_hip_devfeatures* f = new (std::nothrow) popsift_hip_devfeatures();
+    if (!f) return POPSIFT_HIP_ERR_OOM;
+    f->device = device;
+    f->n_feat = n_feat;
+    f->n_desc = n_desc;
+    const size_t bf = sizeof(DevFeature) * (size_t)std::max(n_feat, 1);
+    const size_t bd = sizeof(float) * 128 * (size_t)std::max(n_desc, 1);
+    const size_t br = sizeof(int) * (size_t)std::max(n_desc, 1);
+    const bool   ok = hipMalloc((void**)&f->d_feat, bf) == hipSuccess && hipMalloc((void**)&f->d_desc, bd) == hipSuccess &&
+                    hipMalloc((void**)&f->d_rev, br) == hipSuccess && hipMemset(f->d_feat, 0, bf) == hipSuccess &&
+                    hipMemset(f->d_desc, 0, bd) == hipSuccess && hipMemset(f->d_rev, 0, br) == hipSuccess;
+    if (!ok) {
+        popsift_hip_devfeatures_free(f);
+        return POPSIFT_HIP_ERR_OOM;
+    }
+    *out = f;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_devfeatures_from_host(int device, const float* desc, int n, popsift_hip_devfeatures** out)
+{
+    if (!out || n < 0 || (n > 0 && !desc)) return POPSIFT_HIP_ERR_INVALID;
+    *out = nullptr;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return POPSIFT_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= nd) return POPSIFT_HIP_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return POPSIFT_HIP_ERR_DEVICE;
+    popsift_hip_devfeatures* f = new (std::nothrow) popsift_hip_devfeatures();
+    if (!f) return POPSIFT_HIP_ERR_OOM;
+    f->device = device;
+    f->n_feat = 0;
+    f->n_desc = n;
+    bool ok = hipMalloc((void**)&f->d_feat, sizeof(DevFeature)) == hipSuccess &&
+              hipMalloc((void**)&f->d_desc, sizeof(float) * 128 * (size_t)std::max(n, 1)) == hipSuccess &&
+              hipMalloc((void**)&f->d_rev, sizeof(int) * (size_t)std::max(n, 1)) == hipSuccess;
+    if (ok && n > 0) {
+        ok = hipMemcpy(f->d_desc, desc, sizeof(float) * 128 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemset(f->d_rev, 0xff, sizeof(int) * (size_t)n) == hipSuccess; /* -1: no feature behind it */
+    }
+    if (!ok) {
+        popsift_hip_devfeatures_free(f);
+        return POPSIFT_HIP_ERR_OOM;
+    }
+    *out = f;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_devfeatures_download(const popsift_hip_devfeatures* f, float* desc, int32_t* rev)
+{
+    if (!f) return POPSIFT_HIP_ERR_INVALID;
+    if (hipSetDevice(f->device) != hipSuccess) return POPSIFT_HIP_ERR_DEVICE;
+    if (f->n_desc > 0) {
+        if (desc && hipMemcpy(desc, f->d_desc, sizeof(float) * 128 * (size_t)f->n_desc, hipMemcpyDeviceToHost) != hipSuccess)
+            return POPSIFT_HIP_ERR_DEVICE;
+        if (rev && hipMemcpy(rev, f->d_rev, sizeof(int) * (size_t)f->n_desc, hipMemcpyDeviceToHost) != hipSuccess)
+            return POPSIFT_HIP_ERR_DEVICE;
+    }
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_match_sets(const popsift_hip_devfeatures* lc, const popsift_hip_devfeatures* r, popsift_hip_match* out)
+{
+    if (!lc || !r || (lc->n_desc > 0 && !out)) return POPSIFT_HIP_ERR_INVALID;
+    if (lc->n_desc == 0) return POPSIFT_HIP_OK;
+    /* the scratch buffers live in the left set (one match at a time per left set, like one image at a time per context) */
+    popsift_hip_devfeatures* l = const_cast<popsift_hip_devfeatures*>(lc);
+    if (hipSetDevice(l->device) != hipSuccess) return POPSIFT_HIP_ERR_DEVICE;
+    const float* rdesc = r->d_desc;
+    float*       r_copy = nullptr;
+    int          rc = POPSIFT_HIP_OK;
+    auto         ok = [&](hipError_t e) {
+        if (e != hipSuccess && rc == POPSIFT_HIP_OK) rc = (e == hipErrorOutOfMemory) ? POPSIFT_HIP_ERR_OOM : POPSIFT_HIP_ERR_DEVICE;
+        return e == hipSuccess;
+    };
+    const size_t out_bytes = sizeof(popsift_hip_match) * (size_t)l->n_desc;
+    if (!l->m_stream) {
+        hipStream_t s = nullptr;
+        if (ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking))) l->m_stream = s;
+    }
+    if (rc == POPSIFT_HIP_OK && !l->m_out) ok(hipMalloc(&l->m_out, out_bytes));
+    if (rc == POPSIFT_HIP_OK && !l->m_host) ok(hipHostMalloc(&l->m_host, out_bytes, hipHostMallocDefault));
+    const int    n_split = match_splits(l->n_desc, r->n_desc);
+    const size_t need = match_partial_bytes(l->n_desc, n_split);
+    if (rc == POPSIFT_HIP_OK && need > l->m_partial_cap) {
+        if (l->m_partial) (void)hipFree(l->m_partial);
+        l->m_partial = nullptr;
+        l->m_partial_cap = 0;
+        if (ok(hipMalloc(&l->m_partial, need))) l->m_partial_cap = need;
+    }
+    if (rc == POPSIFT_HIP_OK && r->device != l->device && r->n_desc > 0) {
+        /* images of one PopSift object may have been extracted on different GPUs: bring the right set over (xGMI) */
+        const size_t bytes = sizeof(float) * 128 * (size_t)r->n_desc;
+        if (ok(hipMalloc((void**)&r_copy, bytes)) && ok(hipMemcpyPeer(r_copy, l->device, r->d_desc, r->device, bytes)))
+            rdesc = r_copy;
+    }
+    hipStream_t s = (hipStream_t)l->m_stream;
+    if (rc == POPSIFT_HIP_OK &&
+        ok(launch_match(l->d_desc, l->n_desc, rdesc, r->n_desc, n_split, l->m_partial, (popsift_hip_match*)l->m_out, s)) &&
+        ok(hipMemcpyAsync(l->m_host, l->m_out, out_bytes, hipMemcpyDeviceToHost, s)) && ok(hipStreamSynchronize(s)))
+        memcpy(out, l->m_host, out_bytes);
+    if (r_copy) (void)hipFree(r_copy);
+    return rc;
 }
 
 void* popsift_hip_host_alloc(size_t bytes)

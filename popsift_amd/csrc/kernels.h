@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "sift_types.h"
 
 namespace popsift_hip {
@@ -49,5 +51,13 @@ bool       filter_supported(int n_oct, int max_extrema, int grid_size);
 size_t     filter_hist_bytes(int grid_size);
 hipError_t launch_filter(int n_oct, const SiftConsts& sc, Counters* ct, const InitExt* iext, InitExt* iext_out,
                          FilterState* fs, int* hist, hipStream_t s);
+
+/* match.hip: brute-force 2-NN (features.cu:157-300) */
+int        match_splits(int l_len, int r_len);
+size_t     match_partial_bytes(int l_len, int n_split);
+hipError_t launch_match(const float* ldesc, int l_len, const float* rdesc, int r_len, int n_split, void* partial,
+                        popsift_hip_match* out, hipStream_t s);
+/* Feature records (72-byte popsift::Feature layout) with device descriptor pointers for a cloned set */
+hipError_t launch_clone_features(const popsift_hip_feature* feats, int n_feat, float* desc_base, void* out, hipStream_t s);
 
 }  // namespace popsift_hip

@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#include "cli_options.h"
 #include "pgmread.h"
 
 using namespace std;
@@ -41,106 +42,20 @@ static bool   pgmread_loading = false;
 static bool   float_mode = false;
 static string output_file = "output-features.txt";
 
-namespace {
-
-struct Option {
-    string                             name;  /* long name without the dashes */
-    char                               shrt;  /* 0 = none */
-    bool                               takes_value;
-    string                             group;
-    string                             help;
-    function<void(const string&)>      apply; /* value, or "" for a switch */
-};
-
-[[noreturn]] void usage_error(const vector<Option>& opts, const string& what);
-
-void print_options(ostream& o, const vector<Option>& opts)
-{
-    string group;
-    for (const Option& op : opts) {
-        if (op.group != group) {
-            group = op.group;
-            o << endl << group << ":" << endl;
-        }
-        string left = "  ";
-        if (op.shrt) left += string("-") + op.shrt + " [ --" + op.name + " ]";
-        else left += "--" + op.name;
-        if (op.takes_value) left += " arg";
-        o << left;
-        if (!op.help.empty()) {
-            if (left.size() < 28) o << string(28 - left.size(), ' ');
-            else o << endl << string(28, ' ');
-            /* continuation lines of multi-line help texts are indented like the first */
-            for (char c : op.help) {
-                o << c;
-                if (c == '\n') o << string(28, ' ');
-            }
-        }
-        o << endl;
-    }
-}
-
-[[noreturn]] void usage_error(const vector<Option>& opts, const string& what)
-{
-    /* main.cpp:139-144 */
-    cerr << "Error: " << what << endl << endl << "Usage:\n\nAllowed options:";
-    print_options(cerr, opts);
-    cerr << endl;
-    exit(EXIT_FAILURE);
-}
-
-const Option* find_long(const vector<Option>& opts, const string& name)
-{
-    const Option* hit = 0;
-    int           hits = 0;
-    for (const Option& op : opts) {
-        if (op.name == name) return &op;
-        if (op.name.compare(0, name.size(), name) == 0) {
-            hit = &op;
-            hits++;
-        }
-    }
-    if (hits > 1) usage_error(opts, "option '--" + name + "' is ambiguous");
-    return hits == 1 ? hit : 0;
-}
-
-float to_float(const vector<Option>& opts, const string& name, const string& v)
-{
-    char*       end = 0;
-    const float f = strtof(v.c_str(), &end);
-    if (end == v.c_str() || *end != 0) usage_error(opts, "the argument ('" + v + "') for option '--" + name + "' is invalid");
-    return f;
-}
-
-int to_int(const vector<Option>& opts, const string& name, const string& v)
-{
-    char*      end = 0;
-    const long i = strtol(v.c_str(), &end, 10);
-    if (end == v.c_str() || *end != 0) usage_error(opts, "the argument ('" + v + "') for option '--" + name + "' is invalid");
-    return (int)i;
-}
-
-}  // namespace
-
 static void parseargs(int argc, char** argv, popsift::Config& config, string& inputFile)
 {
-    vector<Option> opts;
-    bool           want_help = false;
-    auto           flag = [&](const string& n, char s, const string& g, const string& h, function<void()> f) {
-        opts.push_back(Option{n, s, false, g, h, [f](const string&) { f(); }});
+    cli::Options opts;
+    auto         flag = [&](const string& n, char s, const string& g, const string& h, function<void()> f) {
+        opts.flag(n, s, g, h, f);
     };
     auto val = [&](const string& n, char s, const string& g, const string& h, function<void(const string&)> f) {
-        opts.push_back(Option{n, s, true, g, h, f});
+        opts.val(n, s, g, h, f, n == "input-file");
     };
-    auto fval = [&](const string& n, const string& g, const string& h, function<void(float)> f) {
-        val(n, 0, g, h, [&opts, n, f](const string& v) { f(to_float(opts, n, v)); });
-    };
-    auto ival = [&](const string& n, const string& g, const string& h, function<void(int)> f) {
-        val(n, 0, g, h, [&opts, n, f](const string& v) { f(to_int(opts, n, v)); });
-    };
+    auto fval = [&](const string& n, const string& g, const string& h, function<void(float)> f) { opts.fval(n, g, h, f); };
+    auto ival = [&](const string& n, const string& g, const string& h, function<void(int)> f) { opts.ival(n, g, h, f); };
 
     /* main.cpp:51-60 */
-    flag("help", 'h', "Options", "Print usage", [&] { want_help = true; });
+    flag("help", 'h', "Options", "Print usage", [] {});
     flag("verbose", 'v', "Options", "", [&] { config.setVerbose(); });
     flag("log", 'l', "Options", "Write debugging files", [&] { config.setLogMode(popsift::Config::All); });
     val("input-file", 'i', "Options", "Input file", [&](const string& v) { inputFile = v; });
@@ -211,52 +126,7 @@ static void parseargs(int argc, char** argv, popsift::Config& config, string& in
         [&](const string& s) { output_file = s; });
     ival("max-extrema", "Extensions", "Extrema kept per octave (default 100000)", [&](int v) { config.setMaxExtrema(v); });
 
-    bool have_input = false;
-    for (int i = 1; i < argc; i++) {
-        const string  a = argv[i];
-        const Option* op = 0;
-        string        value;
-        bool          has_value = false;
-        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
-            string       name = a.substr(2);
-            const size_t eq = name.find('=');
-            if (eq != string::npos) {
-                value = name.substr(eq + 1);
-                name = name.substr(0, eq);
-                has_value = true;
-            }
-            op = find_long(opts, name);
-            if (!op) usage_error(opts, "unrecognised option '--" + name + "'");
-        } else if (a.size() >= 2 && a[0] == '-' && a[1] != '-') {
-            for (const Option& o : opts)
-                if (o.shrt == a[1]) op = &o;
-            if (!op) usage_error(opts, "unrecognised option '" + a + "'");
-            if (a.size() > 2) { /* -ifile */
-                value = a.substr(2);
-                has_value = true;
-            }
-        } else {
-            usage_error(opts, "too many positional options have been specified on the command line");
-        }
-        if (op->takes_value) {
-            if (!has_value) {
-                if (i + 1 >= argc) usage_error(opts, "the required argument for option '--" + op->name + "' is missing");
-                value = argv[++i];
-            }
-            if (op->name == "input-file") have_input = true;
-            op->apply(value);
-        } else {
-            if (has_value) usage_error(opts, "option '--" + op->name + "' does not take any arguments");
-            op->apply("");
-        }
-    }
-    if (want_help) { /* main.cpp:132-135 */
-        cout << "Allowed options:";
-        print_options(cout, opts);
-        cout << '\n';
-        exit(1);
-    }
-    if (!have_input) usage_error(opts, "the option '--input-file' is required but missing");
+    opts.parse(argc, argv);
 }
 
 static void collectFilenames(list<string>& inputFiles, const filesystem::path& inputFile)

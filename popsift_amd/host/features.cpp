@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <iomanip>
 #include <map>
@@ -156,6 +157,102 @@ std::ostream& operator<<(std::ostream& ostr, const Feature& feature)
 {
     feature.print(ostr, false);
     return ostr;
+}
+
+/* ------------------------------------------------------------------------ FeaturesDev */
+
+namespace {
+[[noreturn]] void dev_fatal(const char* what, int rc)
+{
+    std::cerr << __FILE__ << std::endl << "E    " << what << ": " << popsift_hip_strerror(rc) << std::endl;
+    exit(-1);
+}
+}  // namespace
+
+FeaturesDev::FeaturesDev() : _set(0) {}
+
+FeaturesDev::FeaturesDev(int num_ext, int num_ori) : _set(0) { reset(num_ext, num_ori); }
+
+FeaturesDev::FeaturesDev(popsift_hip_devfeatures* adopt) : _set(adopt)
+{
+    int nf = 0, nd = 0;
+    if (_set) popsift_hip_devfeatures_info(_set, 0, &nf, &nd);
+    setFeatureCount(nf);
+    setDescriptorCount(nd);
+}
+
+FeaturesDev::~FeaturesDev() { popsift_hip_devfeatures_free(_set); }
+
+/* features.cu:148-160 */
+void FeaturesDev::reset(int num_ext, int num_ori)
+{
+    int dev = 0;
+    if (_set) popsift_hip_devfeatures_info(_set, &dev, 0, 0);
+    popsift_hip_devfeatures_free(_set);
+    _set = 0;
+    const int rc = popsift_hip_devfeatures_alloc(dev, num_ext, num_ori, &_set);
+    if (rc != POPSIFT_HIP_OK) dev_fatal("cannot allocate device feature arrays", rc);
+    setFeatureCount(num_ext);
+    setDescriptorCount(num_ori);
+}
+
+Feature* FeaturesDev::getFeatures()
+{
+    void* p = 0;
+    if (_set) popsift_hip_devfeatures_ptrs(_set, &p, 0, 0);
+    return (Feature*)p;
+}
+Descriptor* FeaturesDev::getDescriptors()
+{
+    void* p = 0;
+    if (_set) popsift_hip_devfeatures_ptrs(_set, 0, &p, 0);
+    return (Descriptor*)p;
+}
+int* FeaturesDev::getReverseMap()
+{
+    void* p = 0;
+    if (_set) popsift_hip_devfeatures_ptrs(_set, 0, 0, &p);
+    return (int*)p;
+}
+int FeaturesDev::getDevice() const
+{
+    int dev = 0;
+    if (_set) popsift_hip_devfeatures_info(_set, &dev, 0, 0);
+    return dev;
+}
+
+std::vector<FeaturesDev::Match> FeaturesDev::matchAndGet(FeaturesDev* other)
+{
+    std::vector<Match> res;
+    if (!_set || !other || !other->_set) return res;
+    const int                      l_len = getDescriptorCount();
+    std::vector<popsift_hip_match> raw((size_t)l_len);
+    const int                      rc = popsift_hip_match_sets(_set, other->_set, raw.data());
+    if (rc != POPSIFT_HIP_OK) dev_fatal("matching failed", rc);
+    res.resize((size_t)l_len);
+    for (int i = 0; i < l_len; i++) {
+        const popsift_hip_match& m = raw[(size_t)i];
+        res[(size_t)i] = Match{m.best, m.second, m.accept != 0, m.dist_best, m.dist_second};
+    }
+    return res;
+}
+
+/* FeaturesDev::match + show_distance (features.cu:222-300): the reference prints from the device */
+void FeaturesDev::match(FeaturesDev* other)
+{
+    const std::vector<Match> m = matchAndGet(other);
+    const int                l_len = getDescriptorCount();
+    const int                r_len = other ? other->getDescriptorCount() : 0;
+    if (l_len == 0 || r_len == 0) return;
+    std::vector<int> l_fem((size_t)l_len), r_fem((size_t)r_len);
+    popsift_hip_devfeatures_download(_set, 0, l_fem.data());
+    popsift_hip_devfeatures_download(other->_set, 0, r_fem.data());
+    for (int i = 0; i < l_len; i++) {
+        const Match& x = m[(size_t)i];
+        printf("%s feat %4d [%4d] matches feat %4d [%4d] ( 2nd feat %4d [%4d] ) dist %.3f vs %.3f\n",
+               x.accept ? "accept" : "reject", l_fem[(size_t)i], i, r_fem[(size_t)x.best], x.best,
+               r_fem[(size_t)x.second], x.second, x.dist_best, x.dist_second);
+    }
 }
 
 }  // namespace popsift

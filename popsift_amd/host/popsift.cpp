@@ -129,8 +129,7 @@ popsift::FeaturesDev*  SiftJob::getDev() { return dynamic_cast<popsift::Features
 PopSift::PopSift(const popsift::Config& config, popsift::Config::ProcessingMode mode, ImageMode imode)
     : _image_mode(imode)
 {
-    if (mode != popsift::Config::ExtractingMode)
-        DIE("MatchingMode (device-resident features + matcher) is not part of this build");
+    _proc_mode = mode;
     configure(config, true);
 }
 
@@ -207,6 +206,15 @@ void PopSift::worker_loop(Worker* me)
         int nf = 0, nd = 0;
         if (rc == POPSIFT_HIP_OK) rc = popsift_hip_wait(me->ctx, &nf, &nd);
         if (rc != POPSIFT_HIP_OK) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
+
+        if (_proc_mode == popsift::Config::MatchingMode) {
+            /* matchPrepareLoop (popsift.cpp:215-236): the results stay on the GPU */
+            popsift_hip_devfeatures* set = 0;
+            rc = popsift_hip_clone_results(me->ctx, &set);
+            if (rc != POPSIFT_HIP_OK) DIE(string("cloning device results failed: ") + popsift_hip_last_error(me->ctx));
+            job->setFeatures(new popsift::FeaturesDev(set));
+            continue;
+        }
 
         popsift::FeaturesHost* features = new popsift::FeaturesHost(nf, nd);
         if (nd == 0) cerr << "Warning: no descriptors extracted" << endl; /* sift_desc.cu:88-92 */

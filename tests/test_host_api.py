@@ -25,7 +25,9 @@ def test_host_library_exports_the_class_api():
                 "SiftJob::getHost()", "SiftJob::getDev()", "popsift::Config::Config()",
                 "popsift::Config::setGaussMode(", "popsift::Config::setDescMode(", "popsift::Config::setNormMode(",
                 "popsift::Config::equal(popsift::Config const&) const", "popsift::FeaturesHost::reset(int, int)",
-                "popsift::FeaturesHost::print(", "popsift::Feature::print("):
+                "popsift::FeaturesHost::print(", "popsift::Feature::print(",
+                "popsift::FeaturesDev::match(popsift::FeaturesDev*)", "popsift::FeaturesDev::reset(int, int)",
+                "popsift::FeaturesDev::getReverseMap()", "popsift::cuda::device_prop_t::set(int, bool)"):
         assert sym in out, sym
 
 
@@ -141,6 +143,45 @@ def test_demo_modes_filter_and_log_dumps(gpu_hip, tmp_path):
     assert np.array_equal(np.array(txt[4:], int).reshape(h0, w0), ctx.plane(0, 1, 1).astype(np.int32) + 127)
     assert len(open(str(tmp_path / "dir-desc" / "desc-pyramid.txt")).read().splitlines()) == len(desc)
     assert len(open(str(tmp_path / "dir-fpt" / "desc-pyramid.txt")).read().splitlines()) == len(desc)
+
+
+@pytest.mark.gpu
+def test_match_program(gpu_hip, oracle_mod, tmp_path):
+    """popsift-match (match.cpp:229-276): MatchingMode extraction of two images + FeaturesDev::match,
+    one accept/reject line per left descriptor, against C-ABI extraction + the oracle's matcher."""
+    import re
+    from popsift_amd.synth import synth
+    a = synth(95, 240, 180)
+    b = np.roll(a, (2, 4), axis=(0, 1))
+    pa, pb = str(tmp_path / "l.pgm"), str(tmp_path / "r.pgm")
+    _write_pgm(pa, a)
+    _write_pgm(pb, b)
+    r = subprocess.run([os.path.join(PKG, "popsift-match"), "-l", pa, "--right=" + pb], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    fa, da = gpu_hip.Context().submit(a).fetch()
+    fb, db = gpu_hip.Context().submit(b).fetch()
+    lines = r.stdout.splitlines()
+    assert lines[0] == pa + " <-> " + pb
+    assert lines[1:5] == ["Number of features:    %d" % len(fa), "Number of descriptors: %d" % len(da),
+                          "Number of features:    %d" % len(fb), "Number of descriptors: %d" % len(db)]
+    rows = lines[5:]
+    assert len(rows) == len(da)
+    # feature order inside an octave is compaction order (differs run to run): compare as multisets of
+    # (accept, left position, best position) through the descriptor -> feature maps
+    mo = oracle_mod.match(da, db)
+    rev_a = np.concatenate([[i] * int(f["num_ori"]) for i, f in enumerate(fa)])
+    rev_b = np.concatenate([[i] * int(f["num_ori"]) for i, f in enumerate(fb)])
+    pat = re.compile(r"(accept|reject) feat +(\d+) \[ *(\d+)\] matches feat +(\d+) \[ *(\d+)\] \( 2nd feat +(\d+) \[ *(\d+)\] \) dist ([0-9.]+) vs ([0-9.]+)")
+    got = []
+    for i, row in enumerate(rows):
+        m = pat.match(row)
+        assert m, row
+        assert int(m.group(3)) == i
+        got.append((m.group(1), m.group(8), m.group(9)))
+    want = [("accept" if x["accept"] else "reject", "%.3f" % x["dist_best"], "%.3f" % x["dist_second"]) for x in mo]
+    assert sorted(got) == sorted(want)
+    assert sum(1 for g in got if g[0] == "accept") > len(got) // 4
 
 
 def test_demo_command_line_errors():

@@ -1,0 +1,22 @@
+"""Wall time of popsift_hip_match_sets (allocations, both kernels, result download) for a few set sizes."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from popsift_amd import _capi as hip
+
+rng = np.random.default_rng(0)
+SIZES = ((1000, 1000), (5000, 5000), (20000, 20000), (95000, 95000))
+if len(sys.argv) > 1:
+    SIZES = ((int(sys.argv[1]), int(sys.argv[1])),)
+for nl, nr in SIZES:
+    l = rng.random((nl, 128), np.float32); l /= np.linalg.norm(l, axis=1, keepdims=True)
+    r = rng.random((nr, 128), np.float32); r /= np.linalg.norm(r, axis=1, keepdims=True)
+    L, R = hip.DevFeatures.from_host(l), hip.DevFeatures.from_host(r)
+    L.match(R)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); m = L.match(R); ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    pairs = nl * nr
+    print("match %6d x %6d: %8.3f ms  %7.1f Gpairs/s  %6.1f TFLOP/s (3 flop x 128 per pair)  accept %.3f" % (
+        nl, nr, t * 1e3, pairs / t / 1e9, pairs * 384 / t / 1e12, m["accept"].mean()), flush=True)

@@ -70,6 +70,7 @@ struct popsift_hip_ctx {
     float*  d_arena = nullptr;
     size_t  arena_cap = 0; /* floats */
     PyrDesc pd{};
+    int      ori_blocks = 8192, desc_blocks = 16384; /* grid-stride workgroups of the keypoint kernels */
     InitExt* d_iext = nullptr;
     InitExt* d_iext2 = nullptr;      /* grid filter output (filter enabled only) */
     FilterState* d_fstate = nullptr;
@@ -394,11 +395,11 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
         /* Pyramid::orientation's filter hook (s_orientation.cu:353-367); the 10 % test is taken on the device */
         HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->d_ct, c->d_iext, c->d_iext2, c->d_fstate, c->d_fhist, c->stream));
     }
-    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ext, 8192, c->stream));
+    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ext, c->ori_blocks, c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->desc_cap,
                            c->stream));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, 16384,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, c->desc_blocks,
                                   c->stream));
     HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
@@ -642,6 +643,8 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
     c->levels = std::max(2, p->levels); /* popsift.cpp:71 */
     c->L = c->levels + 3;
     c->frozen_octaves = p->octaves;
+    if (const char* e = getenv("POPSIFT_HIP_ORI_BLOCKS")) c->ori_blocks = std::max(atoi(e), 64);   /* tuning knobs */
+    if (const char* e = getenv("POPSIFT_HIP_DESC_BLOCKS")) c->desc_blocks = std::max(atoi(e), 64);
     init_tables(c);
     int rc = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));

@@ -35,6 +35,9 @@ CASES = [
     ("grid_descriptor", dict(desc_mode=2), (28, 240, 180)),
     ("grid_descriptor_vlfeat_classic", dict(desc_mode=2, sift_mode=2, norm_mode=1), (29, 200, 150)),
     ("notile_descriptor", dict(desc_mode=4), (30, 240, 180)),
+    ("deep_octaves_40x24", dict(octaves=7), (40, 40, 24)),                  # planes shrink to 2x1
+    ("tile_edge_257x129_no_upscale", dict(upscale_factor=0.0), (41, 257, 129)),
+    ("tall_9x300", dict(), (42, 9, 300)),
     ("notile_descriptor_opencv_classic", dict(desc_mode=4, sift_mode=1, norm_mode=1, norm_multi=9), (31, 200, 150)),
 ]
 
@@ -101,6 +104,37 @@ def test_float_images(oracle_mod, gpu_hip):
     orc, ctx = run_both(oracle_mod, gpu_hip, {}, img)
     assert_planes_equal(orc, ctx, 3)
     assert_keypoints_match(orc, ctx)
+
+
+def test_pitched_host_and_device_images(oracle_mod, gpu_hip):
+    """pitch > width through the C ABI, for byte and float images, host and device resident."""
+    import ctypes as C
+    rt = C.CDLL("libamdhip64.so")              # the HIP runtime libpopsift_hip.so itself is linked against
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    img = synth(43, 150, 100)
+    orc = oracle_mod.Oracle(oracle_mod.default_params(), threads=8).run(img)
+    want = sorted_features(*orc.fetch())
+    L = gpu_hip.lib()
+    for dtype, fn_h, fn_d in ((np.uint8, L.popsift_hip_submit_u8, L.popsift_hip_submit_dev_u8),
+                              (np.float32, L.popsift_hip_submit_f32, L.popsift_hip_submit_dev_f32)):
+        src = img if dtype == np.uint8 else (img.astype(np.float32) / 255.0)
+        ref = want if dtype == np.uint8 else sorted_features(*oracle_mod.Oracle(oracle_mod.default_params(), threads=8).run(src).fetch())
+        padded = np.full((100, 192), 77, dtype)
+        padded[:, :150] = src
+        ctx = gpu_hip.Context()
+        assert fn_h(ctx._h, padded.ctypes.data, 150, 100, 192) == 0
+        got = sorted_features(*ctx.fetch())
+        assert np.array_equal(got[0]["xpos"], ref[0]["xpos"]) and np.array_equal(got[0]["ypos"], ref[0]["ypos"])
+        dev = C.c_void_p()
+        assert rt.hipMalloc(C.byref(dev), padded.nbytes) == 0
+        assert rt.hipMemcpy(dev, padded.ctypes.data, padded.nbytes, 1) == 0      # hipMemcpyHostToDevice
+        assert fn_d(ctx._h, dev, 150, 100, 192) == 0
+        got2 = sorted_features(*ctx.fetch())
+        assert np.array_equal(got2[0]["xpos"], ref[0]["xpos"]) and np.array_equal(bits(got2[1]), bits(got[1]))
+        ctx.close()
+        rt.hipFree(dev)
 
 
 def test_analytic_blob(gpu_hip):

@@ -7,10 +7,13 @@ cd $R/popsift_amd/csrc && make -s || exit 1
 i=0
 for V in "$@"; do
   i=$((i+1))
-  for f in ctx pyramid extrema keypoint; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $V -c $f.hip -o /tmp/var_$f.o || exit 1
+  OBJS=""
+  for f in $(sed -n 's/^SRCS *= *//p' Makefile); do
+    b=${f%.hip}
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $V -c $f -o /tmp/var_$b.o || exit 1
+    OBJS="$OBJS /tmp/var_$b.o"
   done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/v$i.so /tmp/var_ctx.o /tmp/var_pyramid.o /tmp/var_extrema.o /tmp/var_keypoint.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/v$i.so $OBJS || exit 1
   echo "v$i: $V" >> $R/build_variants/flags.txt
 done
 cat $R/build_variants/flags.txt

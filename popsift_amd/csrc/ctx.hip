@@ -293,7 +293,10 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
         return rc;
-    if (int rc = ensure_cand_cap(c, 1 << 20)) return rc;
+    {
+        const char* e = getenv("POPSIFT_HIP_CAND_CAP"); /* test hook: start small to exercise the regrow path */
+        if (int rc = ensure_cand_cap(c, e ? std::max(atoi(e), DET_SUBQ) : (1 << 20))) return rc;
+    }
     if (int rc = grow(c, &c->d_ovf, &c->ovf_cap, (size_t)tiles + 1)) return rc;
     /* the stream is idle here (submit drains the previous image first), so h_pd is free to reuse */
     *c->h_pd = c->pd;
@@ -460,14 +463,16 @@ int finish(popsift_hip_ctx* c)
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const bool desc_short = c->h_ct->ori_total > c->desc_cap;
-        const bool cand_short = c->h_ct->pad[0] > c->cand_cap;
+        int qmax = 0;
+        for (int q = 0; q < DET_SUBQ; q++) qmax = std::max(qmax, c->h_ct->qcnt[q]);
+        const bool cand_short = qmax > c->cand_cap / DET_SUBQ;
         if (!desc_short && !cand_short) break;
         /* more candidates / descriptors than the buffers hold (the reference reallocates between
          * stages, sift_pyramid.cu:179-209): grow and redo the keypoint stages of this image */
         if (desc_short)
             if (int rc = ensure_desc_cap(c, c->h_ct->ori_total + c->h_ct->ori_total / 8 + 1024)) return rc;
         if (cand_short)
-            if (int rc = ensure_cand_cap(c, c->h_ct->pad[0] + c->h_ct->pad[0] / 8 + 1024)) return rc;
+            if (int rc = ensure_cand_cap(c, DET_SUBQ * (qmax + qmax / 8 + 64))) return rc;
         if (int rc = enqueue_keypoint_stages(c)) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     }

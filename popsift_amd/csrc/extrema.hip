@@ -292,7 +292,10 @@ struct RowRed {
  * seen outside synthetic stress images; typical is ~50) is handed to the SLOW instantiation of this
  * kernel, which re-does it with a flush per row.
  */
-constexpr int DET_G = 4;   /* rows per load group */
+#ifndef DET_GROUP
+#define DET_GROUP 4
+#endif
+constexpr int DET_G = DET_GROUP;   /* rows per load group */
 constexpr int DET_Q = 512; /* per-wave candidate queue (entries) */
 
 template <int MODE, int LEVELS, bool SLOW>
@@ -336,11 +339,12 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             if (n == 0) return 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int basei = 0;
-            if (lane == 0) basei = atomicAdd(&ct->pad[0], n);
+            const int subq = blockIdx.x & (DET_SUBQ - 1), seg = cand_cap / DET_SUBQ;
+            int       basei = 0;
+            if (lane == 0) basei = atomicAdd(&ct->qcnt[subq], n);
             basei = __shfl(basei, 0);
             for (int i = lane; i < n; i += 64)
-                if (basei + i < cand_cap) cand[basei + i] = queue[i];
+                if (basei + i < seg) cand[(size_t)subq * seg + basei + i] = queue[i];
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             return 0;
@@ -436,6 +440,22 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             }
             flush(n_buf);
         } else {
+#ifdef DET_PIPE
+            /* two register buffers: the loads of the next group are in flight while a group is consumed */
+            float q0[DET_G][3 * NP], q1[DET_G][3 * NP];
+#pragma unroll
+            for (int k = 0; k < DET_G; k++) fetch_row(min(yb + k + 1, ye + 1), q0[k]);
+            for (int y0 = yb; y0 <= ye; y0 += 2 * DET_G) {
+#pragma unroll
+                for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + DET_G + k + 1, ye + 1), q1[k]);
+#pragma unroll
+                for (int k = 0; k < DET_G; k++) step(y0 + k, q0[k]);
+#pragma unroll
+                for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + 2 * DET_G + k + 1, ye + 1), q0[k]);
+#pragma unroll
+                for (int k = 0; k < DET_G; k++) step(y0 + DET_G + k, q1[k]); /* rows past ye cannot hit */
+            }
+#else
             for (int y0 = yb; y0 <= ye; y0 += DET_G) {
                 float q[DET_G][3 * NP];
 #pragma unroll
@@ -443,6 +463,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) step(y0 + k, q[k]);
             }
+#endif
             if (overflow) {
                 /* too many candidates for the queue: leave the whole strip to the SLOW pass */
                 if (lane == 0) ovf[atomicAdd(&ct->pad[1], 1)] = unit;
@@ -453,51 +474,85 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
     }
 }
 
-/* Refinement of the compacted candidates: one lane per candidate, dense waves. */
+/*
+ * Refinement of the candidates: one lane per candidate in dense waves.  Survivors are appended
+ * to their octave's list with ONE returning global atomic per workgroup, octave and step (LDS counters
+ * gather the four waves first) -- the same hot-counter limit as in the detection kernel.
+ */
 template <int MODE>
 __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
                                                 SiftConsts sc, Counters* __restrict__ ct,
                                                 const int2* __restrict__ cand, int cand_cap,
                                                 InitExt* __restrict__ iext)
 {
-    const int lane = threadIdx.x & 63;
-    const int L = pdp->L;
-    const int total = min(ct->pad[0], cand_cap);
-    /* wave-uniform trip count so that __ballot sees whole waves */
-    for (int i0 = (blockIdx.x * 256 + (threadIdx.x & ~63)); i0 < total; i0 += gridDim.x * 256) {
-        const int i = i0 + lane;
-        bool      found = false;
-        InitExt   ec;
-        int       o = 0;
-        if (i < total) {
-            const int2 cd = cand[i];
-            const int  x = cd.x & 0xffff, y = cd.x >> 16, level = cd.y & 0xff;
-            o = cd.y >> 8;
-            const OctDesc* od = &pdp->o[o];
-            DogView        dog;
-            dog.base = arena + od->dog_off;
-            dog.ps = od->plane_stride;
-            dog.w = od->w;
-            dog.h = od->h;
-            dog.pitch = od->pitch;
-            dog.nl = L - 1;
-            const float val = dog.raw(x, y, level);
-            found = refine<MODE>(dog, sc, x, y, level, val, L - 1, ec);
+    __shared__ int s_cnt[PS_MAX_OCT], s_base[PS_MAX_OCT];
+    __shared__ int s_pref[DET_SUBQ + 1]; /* 256-candidate steps before each sub-queue */
+    const int      lane = threadIdx.x & 63;
+    const int      L = pdp->L, n_oct = pdp->n_oct;
+    const int      seg = cand_cap / DET_SUBQ;
+    if (threadIdx.x < 64) {
+        const int steps = (min(ct->qcnt[lane], seg) + 255) >> 8;
+        int       incl = steps;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int v = __shfl_up(incl, s);
+            if (lane >= s) incl += v;
         }
-        /* wave64 compaction per octave (replaces extrema_count, s_extrema.cu:22-44) */
-        unsigned long long todo = __ballot(found);
-        while (todo) {
-            const int                leader = __ffsll((long long)todo) - 1;
-            const int                lo = __shfl(o, leader);
-            const unsigned long long mask = __ballot(found && o == lo);
-            int                      base = 0;
-            if (lane == leader) base = atomicAdd(&ct->ext_ct[lo], __popcll(mask));
-            base = __shfl(base, leader);
-            if (found && o == lo) {
-                const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                if (idx < sc.max_extrema) iext[(size_t)lo * sc.max_extrema + idx] = ec;
+        s_pref[lane + 1] = incl;
+        if (lane == 0) s_pref[0] = 0;
+    }
+    __syncthreads();
+    const int n_steps = s_pref[DET_SUBQ];
+    /* the steps of all sub-queues form one list that the workgroups share out; trip counts are
+     * workgroup-uniform, so the barriers below are reached by all four waves */
+    {
+        for (int w = blockIdx.x; w < n_steps; w += gridDim.x) {
+            int q = 0;
+            while (s_pref[q + 1] <= w) q++;
+            const int total = min(ct->qcnt[q], seg);
+            const int b0 = (w - s_pref[q]) << 8;
+            if (threadIdx.x < PS_MAX_OCT) s_cnt[threadIdx.x] = 0;
+            __syncthreads();
+            const int i = b0 + threadIdx.x;
+            bool      found = false;
+            InitExt   ec;
+            int       o = 0, slot = 0;
+            if (i < total) {
+                const int2 cd = cand[(size_t)q * seg + i];
+                const int  x = cd.x & 0xffff, y = cd.x >> 16, level = cd.y & 0xff;
+                o = cd.y >> 8;
+                const OctDesc* od = &pdp->o[o];
+                DogView        dog;
+                dog.base = arena + od->dog_off;
+                dog.ps = od->plane_stride;
+                dog.w = od->w;
+                dog.h = od->h;
+                dog.pitch = od->pitch;
+                dog.nl = L - 1;
+                const float val = dog.raw(x, y, level);
+                found = refine<MODE>(dog, sc, x, y, level, val, L - 1, ec);
             }
-            todo &= ~mask;
+            /* wave64 compaction per octave (replaces extrema_count, s_extrema.cu:22-44), wave -> workgroup in LDS */
+            unsigned long long todo = __ballot(found);
+            while (todo) {
+                const int                leader = __ffsll((long long)todo) - 1;
+                const int                lo = __shfl(o, leader);
+                const unsigned long long mask = __ballot(found && o == lo);
+                int                      wbase = 0;
+                if (lane == leader) wbase = atomicAdd(&s_cnt[lo], __popcll(mask));
+                wbase = __shfl(wbase, leader);
+                if (found && o == lo) slot = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+                todo &= ~mask;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < n_oct && s_cnt[threadIdx.x] > 0)
+                s_base[threadIdx.x] = atomicAdd(&ct->ext_ct[threadIdx.x], s_cnt[threadIdx.x]);
+            __syncthreads();
+            if (found) {
+                const int idx = s_base[o] + slot;
+                if (idx < sc.max_extrema) iext[(size_t)o * sc.max_extrema + idx] = ec;
+            }
+            /* s_cnt is reset after the next barrier at the top of the loop; s_base is only read by lanes that found */
         }
     }
 }

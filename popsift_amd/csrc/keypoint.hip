@@ -118,13 +118,16 @@ __device__ __forceinline__ float atan2_acc(float y, float x)
     return (y < 0.0f) ? -r : r;
 }
 
-__global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__ pdp,
+#ifndef KP_NW
+#define KP_NW 1 /* waves per workgroup of k_orientation / k_descriptor: the waves are independent (one keypoint each) */
+#endif
+__global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __restrict__ pdp,
                                                      const float* __restrict__ arena, SiftConsts sc,
                                                      const Counters* __restrict__ ct,
                                                      const InitExt* __restrict__ iext, Ext* __restrict__ ext)
 {
     const int n_oct = pdp->n_oct, L = pdp->L;
-    __shared__ fix64 s_hist[4][PS_ORI_NBINS + 4];
+    __shared__ fix64 s_hist[KP_NW][PS_ORI_NBINS + 4];
     const int        wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     fix64*           hist = s_hist[wave];
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void k_orientation(const PyrDesc* __restrict__
     __syncthreads();
     const int total = ps[n_oct];
 
-    for (int g = blockIdx.x * 4 + wave; g < total; g += gridDim.x * 4) {
+    for (int g = blockIdx.x * KP_NW + wave; g < total; g += gridDim.x * KP_NW) {
         int o = 0;
         while (o + 1 < n_oct && g >= ps[o + 1]) o++;
         const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - ps[o])];
@@ -420,7 +423,7 @@ __device__ __forceinline__ float atan2_bins(float y, float x)
  * a different summation order.  The 128-bin histogram lives in LDS (per wave),
  * is normalised in registers and leaves as two coalesced 256 B rows.
  */
-__global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
+__global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
                                                        const float* __restrict__ arena, SiftConsts sc,
                                                        const Counters* __restrict__ ct, const Ext* __restrict__ ext,
                                                        const int* __restrict__ map, float* __restrict__ desc,
@@ -431,9 +434,9 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
      * copies by lane cuts the same-address serialisation of the LDS atomics */
     constexpr int    DCOPY = 2;
     constexpr int    MAXROWS = 256; /* patch rows handled by the span path */
-    __shared__ fix64 s_hist[4][DCOPY][128];
-    __shared__ int   s_start[4][MAXROWS + 1]; /* flat index of the first sample of each patch row */
-    __shared__ short s_lo[4][MAXROWS];        /* first column of each patch row's span */
+    __shared__ fix64 s_hist[KP_NW][DCOPY][128];
+    __shared__ int   s_start[KP_NW][MAXROWS + 1]; /* flat index of the first sample of each patch row */
+    __shared__ short s_lo[KP_NW][MAXROWS];        /* first column of each patch row's span */
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fix64*           hist = s_hist[wave][lane & (DCOPY - 1)];
     fix64*           hall = s_hist[wave][0];
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256, 8) void k_descriptor(const PyrDesc* __restrict
     const int        total = min(ct->ori_total, desc_cap);
     const int        L = pdp->L;
 
-    for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
+    for (int d = blockIdx.x * KP_NW + wave; d < total; d += gridDim.x * KP_NW) {
         const Ext*     e = ext + map[d];
         const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
         const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __r
 hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
                               const InitExt* iext, Ext* ext, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orientation, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, iext, ext);
+    hipLaunchKernelGGL(k_orientation, dim3(blocks * 4 / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, iext, ext);
     return hipGetLastError();
 }
 
@@ -993,7 +996,7 @@ hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftC
     else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
         hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     else
-        hipLaunchKernelGGL(k_descriptor, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor, dim3(blocks * 4 / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     return hipGetLastError();
 }
 

@@ -73,8 +73,13 @@ struct Counters {
     int ori_ps[PS_MAX_OCT];
     int ext_total;
     int ori_total;
-    int pad[2]; /* [0] candidates found by the detection kernel, [1] strips left to its slow pass */
+    int pad[2]; /* [0] unused, [1] strips left to the slow detection pass */
+    /* The detection kernel appends candidates to DET_SUBQ sub-queues (workgroup index mod DET_SUBQ), each with
+     * its own counter and its own slice of the candidate buffer: a returning atomicAdd on ONE address saturates
+     * near 90/us on MI355X, which cost the kernel 29 of its 106 us (one flush per strip, 5456 strips). */
+    int qcnt[64];
 };
+#define DET_SUBQ 64
 
 /* grid filter working set (filter.hip), device resident */
 #define FILTER_MAX_CELLS 4096 /* grid_size <= 64 */

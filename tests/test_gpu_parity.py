@@ -217,6 +217,20 @@ def test_max_extrema_cap_and_buffer_growth(oracle_mod, gpu_hip):
     assert all(k in allk for k in zip(capped["octave"].tolist(), capped["xpos"].tolist(), capped["ypos"].tolist()))
 
 
+def test_candidate_buffer_regrows(gpu_hip, monkeypatch):
+    """More candidates than a sub-queue slice holds: finish() grows the buffer and redoes the keypoint stages."""
+    img = synth(44, 320, 240)
+    want = sorted_features(*gpu_hip.Context().submit(img).fetch())
+    monkeypatch.setenv("POPSIFT_HIP_CAND_CAP", "256")            # 4 entries per sub-queue
+    ctx = gpu_hip.Context()
+    got = sorted_features(*ctx.submit(img).fetch())
+    monkeypatch.delenv("POPSIFT_HIP_CAND_CAP")
+    assert len(want[0]) > 1000
+    assert np.array_equal(got[0]["xpos"], want[0]["xpos"]) and np.array_equal(bits(got[1]), bits(want[1]))
+    got2 = sorted_features(*ctx.submit(img).fetch())             # grown buffer is kept
+    assert np.array_equal(bits(got2[1]), bits(want[1]))
+
+
 def test_context_reuse_across_sizes_and_determinism(oracle_mod, gpu_hip):
     """One context, images of different sizes (grow-only buffers; the octave count is frozen by
     the first image like popsift.cpp:107-111), and bit-reproducible results run to run."""

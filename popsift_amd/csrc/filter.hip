@@ -89,13 +89,17 @@ __device__ __forceinline__ void locator_init(int* s_ps, const Counters* ct, cons
     __syncthreads();
 }
 
+/* per-cell member counts: LDS histogram per workgroup (NC <= FILTER_MAX_CELLS ints), then one global atomic per
+ * non-empty cell and workgroup -- with a handful of cells a per-wave atomic would hammer a few hot addresses */
 __global__ __launch_bounds__(256) void k_filter_count(int n_oct, SiftConsts sc, const Counters* __restrict__ ct,
                                                       const InitExt* __restrict__ iext, FilterState* __restrict__ fs)
 {
     __shared__ int s_ps[PS_MAX_OCT + 1];
-    locator_init(s_ps, ct, sc, n_oct);
+    __shared__ int s_hist[FILTER_MAX_CELLS];
+    const int      ncell = sc.grid_size * sc.grid_size;
+    for (int c = threadIdx.x; c < ncell; c += 256) s_hist[c] = 0;
+    locator_init(s_ps, ct, sc, n_oct); /* ends with a barrier */
     const int total = s_ps[n_oct];
-    const int ncell = sc.grid_size * sc.grid_size;
     const int span = gridDim.x * 256;
     for (int g0 = blockIdx.x * 256; g0 < total; g0 += span) {
         const int  g = g0 + threadIdx.x;
@@ -107,8 +111,11 @@ __global__ __launch_bounds__(256) void k_filter_count(int n_oct, SiftConsts sc, 
             cell = iext[(size_t)o * sc.max_extrema + (g - s_ps[o])].cell;
             cell = min(max(cell, 0), ncell - 1);
         }
-        wave_agg_inc(fs->cell_count, cell, act);
+        wave_agg_inc(s_hist, cell, act);
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncell; c += 256)
+        if (s_hist[c] > 0) atomicAdd(&fs->cell_count[c], s_hist[c]);
 }
 
 /* The host part of extrema_filter_grid (s_filtergrid.cu:204-262) on one workgroup.
@@ -326,7 +333,7 @@ hipError_t launch_filter(int n_oct, const SiftConsts& sc, Counters* ct, const In
     err = hipMemsetAsync(hist, 0, filter_hist_bytes(sc.grid_size), s);
     if (err != hipSuccess) return err;
     const int sweep = 512; /* grid-stride workgroups of the per-candidate sweeps */
-    hipLaunchKernelGGL(k_filter_count, dim3(sweep), dim3(256), 0, s, n_oct, sc, ct, iext, fs);
+    hipLaunchKernelGGL(k_filter_count, dim3(64), dim3(256), 0, s, n_oct, sc, ct, iext, fs);
     hipLaunchKernelGGL(k_filter_limit, dim3(1), dim3(256), 0, s, n_oct, sc, ct, fs);
     for (int pass = 0; pass < FILTER_PASSES; pass++) {
         hipLaunchKernelGGL(k_filter_hist, dim3(sweep), dim3(256), 0, s, pass, n_oct, sc, ct, iext, fs, hist);

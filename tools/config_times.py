@@ -12,6 +12,7 @@ CONFIGS = [
     ("config 5 stand-in: 850x680 synthetic, OpenCV mode + opencv Gauss", dict(sift_mode=1, gauss_mode=3), (200, 850, 680)),
     ("config 2 with grid descriptor", dict(desc_mode=2), (2, 1920, 1080)),
     ("config 2 with notile descriptor", dict(desc_mode=4), (2, 1920, 1080)),
+    ("config 2 with grid filter 20000 / 4x4 / largest first", dict(filter_max_extrema=20000, filter_sorting=1, filter_grid_size=4), (2, 1920, 1080)),
 ]
 for name, kw, spec in CONFIGS:
     img = synth(*spec)

@@ -8,6 +8,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 img = synth(2, W, H)
-ctx = hip.Context()
+# optional Params overrides: PROF_KW='{"filter_max_extrema": 20000, "filter_sorting": 1, "filter_grid_size": 4}'
+import json
+kw = json.loads(os.environ.get("PROF_KW", "{}"))
+ctx = hip.Context(hip.default_params(**kw))
 for i in range(n):
     ctx.submit(img); c = ctx.wait(); print(c, "%.3f ms" % ctx.report().ms_device, flush=True)

@@ -74,6 +74,9 @@ def run_step(ctxs, ptrs, pool):
         t.join()
 
 
+ROOT = HERE
+
+
 def main():
     args = parse()
     import torch
@@ -201,6 +204,18 @@ def main():
             c0.fetch()
         if n_e2e:
             extra["host_to_host_single_ctx_mpix_s"] = round(n_e2e * W * H / 1e6 / (time.perf_counter() - t1), 1)
+
+        # the same through the drop-in C++ API (PopSift::enqueue ... SiftJob::get, 4 contexts, pinned result pool):
+        # a child process, so that its GPU contexts do not share this one's; reported, never `value`
+        exe = os.path.join(ROOT, "popsift_amd", "popsift-bench")
+        if world == 1 and not args.only_roofline and os.path.exists(exe):
+            import subprocess
+            try:
+                r = subprocess.run([exe, "--images", "64", "--inflight", "16"], capture_output=True, text=True, timeout=120,
+                                   env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE="4", POPSIFT_DEVICES=str(local_rank)))
+                extra["host_to_host_cpp_api"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:  # a reported extra: never fail the bench line over it
+                extra["host_to_host_cpp_api"] = {"error": str(e)[:200]}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not args.only_roofline:

@@ -6,7 +6,7 @@
  *   - uninit() must be called before the PopSift object goes away
  * What differs underneath: no CUDA / Boost in this header; work is spread over
  * every visible MI355X (POPSIFT_DEVICES, default "all") with several extraction
- * contexts per GPU (POPSIFT_CONTEXTS_PER_DEVICE, default 2), each with its own
+ * contexts per GPU (POPSIFT_CONTEXTS_PER_DEVICE, default 4), each with its own
  * HIP stream and buffers, behind the C ABI of popsift_hip.h.  Jobs complete through
  * their own futures, so any number of PopSift objects may coexist in a process.
  */

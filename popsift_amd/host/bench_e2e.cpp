@@ -1,0 +1,95 @@
+/*
+ * popsift-bench -- steady-state throughput of the drop-in C++ API, host image in -> host features out
+ * (SURVEY 8(d) "T_e2e": wall time per image through enqueue() ... get() with many images in flight).
+ * PCIe-inclusive: every image is uploaded and its features + descriptors (about 53 MB for the dense
+ * synthetic 1080p image) are downloaded into a FeaturesHost.  Never the headline `value` of bench.py.
+ *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--seed S]
+ * Contexts per GPU come from POPSIFT_CONTEXTS_PER_DEVICE, GPUs from POPSIFT_DEVICES.
+ */
+#include <popsift/features.h>
+#include <popsift/popsift.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <random>
+#include <vector>
+
+/* a cheap stand-in for popsift_amd/synth.py: smoothed noise plus blobs, deterministic */
+static std::vector<unsigned char> make_image(int w, int h, unsigned seed)
+{
+    std::mt19937                          rng(seed);
+    std::uniform_real_distribution<float> uni(0.0f, 1.0f);
+    std::vector<float>                    a((size_t)w * h), b((size_t)w * h);
+    for (float& v : a) v = uni(rng);
+    for (int pass = 0; pass < 2; pass++) { /* two box blurs */
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int x0 = x > 0 ? x - 1 : x, x1 = x < w - 1 ? x + 1 : x;
+                b[(size_t)y * w + x] = (a[(size_t)y * w + x0] + a[(size_t)y * w + x] + a[(size_t)y * w + x1]) / 3.0f;
+            }
+        for (int y = 0; y < h; y++) {
+            const int y0 = y > 0 ? y - 1 : y, y1 = y < h - 1 ? y + 1 : y;
+            for (int x = 0; x < w; x++)
+                a[(size_t)y * w + x] = (b[(size_t)y0 * w + x] + b[(size_t)y * w + x] + b[(size_t)y1 * w + x]) / 3.0f;
+        }
+    }
+    std::vector<unsigned char> img((size_t)w * h);
+    for (size_t i = 0; i < img.size(); i++) {
+        const float v = 128.0f + (a[i] - 0.5f) * 700.0f;
+        img[i] = (unsigned char)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+    }
+    return img;
+}
+
+int main(int argc, char** argv)
+{
+    int images = 64, w = 1920, h = 1080, inflight = 16;
+    unsigned seed = 1;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--images")) images = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--width")) w = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--height")) h = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--inflight")) inflight = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--seed")) seed = (unsigned)atoi(argv[i + 1]);
+    }
+    std::vector<std::vector<unsigned char>> pool;
+    for (int k = 0; k < 4; k++) pool.push_back(make_image(w, h, seed + k));
+
+    popsift::Config config;
+    PopSift         sift(config, popsift::Config::ExtractingMode, PopSift::ByteImages);
+
+    auto run = [&](int n, long long& feats, long long& descs) {
+        std::deque<SiftJob*> q;
+        feats = descs = 0;
+        auto drain_one = [&]() {
+            SiftJob*           j = q.front();
+            q.pop_front();
+            popsift::Features* f = j->get();
+            feats += f->getFeatureCount();
+            descs += f->getDescriptorCount();
+            delete f;
+            delete j;
+        };
+        for (int i = 0; i < n; i++) {
+            q.push_back(sift.enqueue(w, h, pool[(size_t)i % pool.size()].data()));
+            if ((int)q.size() >= inflight) drain_one();
+        }
+        while (!q.empty()) drain_one();
+    };
+    long long f = 0, d = 0;
+    /* warm-up: device buffers and one pinned result block per job that can be in flight (allocating pinned
+     * memory takes tens of milliseconds per block and stalls every context while it happens) */
+    run(inflight + sift.getContextCount() + 2, f, d);
+    const auto t0 = std::chrono::steady_clock::now();
+    run(images, f, d);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("{\"e2e_host_api_mpix_s\": %.1f, \"images\": %d, \"width\": %d, \"height\": %d, \"contexts\": %d, "
+           "\"in_flight\": %d, \"ms_per_image\": %.3f, \"features_per_image\": %.0f, \"descriptors_per_image\": %.0f}\n",
+           (double)images * w * h / sec / 1e6, images, w, h, sift.getContextCount(), inflight, sec * 1e3 / images,
+           (double)f / images, (double)d / images);
+    sift.uninit();
+    return 0;
+}

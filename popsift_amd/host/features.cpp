@@ -33,9 +33,18 @@ class BlockPool {
     std::mutex                   _m;
     std::multimap<size_t, Block> _free; /* by capacity */
     std::map<void*, Block>       _live;
-    static constexpr size_t      MAX_CACHED = (size_t)2 << 30; /* bytes kept for reuse */
+    /* bytes kept for reuse (POPSIFT_PINNED_CACHE_MB, default 8 GiB): a 1080p result is ~70 MB and every job in
+     * flight holds one, so a small cache makes workers allocate and free pinned memory per image -- calls that
+     * stall the GPU queues of ALL contexts */
+    const size_t                 MAX_CACHED = cache_limit();
     size_t                       _cached = 0;
 
+    static size_t cache_limit()
+    {
+        const char* e = getenv("POPSIFT_PINNED_CACHE_MB");
+        const long  mb = e ? atol(e) : 8192;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }
     static size_t round_up(size_t n)
     {
         size_t c = 4096;

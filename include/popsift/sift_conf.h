@@ -35,7 +35,7 @@ struct Config {
 
     enum ScalingMode { ScaleDirect, ScaleDefault };
 
-    /* Descriptor sampling scheme; this build implements Loop (the default), Grid and NoTile */
+    /* Descriptor sampling scheme (all five are implemented; IGrid shares NoTile's kernel) */
     enum DescMode { Loop, ILoop, Grid, IGrid, NoTile };
 
     /* RootSift = L1-inspired (default), Classic = L2 + 0.2 clamp */

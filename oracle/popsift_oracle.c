@@ -158,8 +158,7 @@ oracle_ctx* oracle_create(const popsift_hip_params* p)
     if (p->gauss_mode != POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE &&
         p->gauss_mode != POPSIFT_HIP_GAUSS_OPENCV_COMPUTE)
         return NULL;
-    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP && p->desc_mode != POPSIFT_HIP_DESC_GRID &&
-        p->desc_mode != POPSIFT_HIP_DESC_NOTILE)
+    if (p->desc_mode < POPSIFT_HIP_DESC_LOOP || p->desc_mode > POPSIFT_HIP_DESC_NOTILE)
         return NULL;
     oracle_ctx* c = (oracle_ctx*)calloc(1, sizeof(*c));
     if (!c) return NULL;
@@ -1123,6 +1122,138 @@ static void descriptor_notile_one(const oracle_ctx* c, const ext_t* e, float ang
         }
 }
 
+/* rotated, interpolated gradient of s_gradiant.h:71-87 at a real position */
+static inline void get_gradiant_rot(float* grad, float* theta, float px, float py, float cos_t, float sin_t,
+                                    const float* layer, int width, int height)
+{
+    const float dxv = tex_linear(layer, width, height, px + cos_t, py + sin_t) -
+                      tex_linear(layer, width, height, px - cos_t, py - sin_t);
+    const float dyv = tex_linear(layer, width, height, px - sin_t, py + cos_t) -
+                      tex_linear(layer, width, height, px + sin_t, py - cos_t);
+    *grad = hypotf(dxv, dyv);
+    *theta = atan2f(dyv, dxv);
+}
+
+/* s_desc_igrid.cu:20-83 ext_desc_igrid_sub, block (16,16,1): the 16 lanes xd of cell (ix, iy) each walk
+ * 16 rows yd of the cell's 16 x 16 sample points (the same 40 x 40 point lattice as notile, cell by cell);
+ * lanes are summed with shuffle_xor 1, 2, 4, 8. */
+static void descriptor_igrid_one(const oracle_ctx* c, const ext_t* e, float ang, float* features)
+{
+    const oct_t* oc = &c->oct[e->octave];
+    const int    width = oc->w, height = oc->h;
+    const float* layer = oc->data[clampi(e->lpos, 0, c->L - 1)];
+    const float  x = e->xpos, y = e->ypos;
+    const float  SBP = fabsf(DESC_MAGNIFY * e->sigma);
+    const float  M_4RPI = 4.0f / F_PI;
+
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (e->sigma == 0) return;
+    const float cos_t = cosf(ang), sin_t = sinf(ang);
+
+    float desc_tile[16];
+    for (int i = 0; i < 16; i++) desc_tile[i] = 1.0f - fabsf(-1.0f + 1.0f / 16.0f + i * 1.0f / 8.0f);
+    const float dn_step = 1.0f / 8.0f, dn_base = 0.5f * dn_step - 20.0f * dn_step;
+
+    for (int iy = 0; iy < 4; iy++)
+        for (int ix = 0; ix < 4; ix++) {
+            float dpt[16][8];
+            memset(dpt, 0, sizeof(dpt));
+            for (int xd = 0; xd < 16; xd++)
+                for (int yd = 0; yd < 16; yd++) {
+                    const float stepx = ix - 2.5f + 1.0f / 16.0f + xd / 8.0f;
+                    const float stepy = iy - 2.5f + 1.0f / 16.0f + yd / 8.0f;
+                    const float ptx = cos_t * stepx + -sin_t * stepy;
+                    const float pty = cos_t * stepy + sin_t * stepx;
+                    float       mod, th;
+                    get_gradiant_rot(&mod, &th, x + ptx * SBP, y + pty * SBP, cos_t, sin_t, layer, width, height);
+                    th += (th < 0.0f ? F_PI2 : 0.0f);
+                    th -= (th >= F_PI2 ? F_PI2 : 0.0f);
+                    const int   gx = ix * 8 + xd, gy = iy * 8 + yd; /* desc_gauss[gy][gx], sift_constants.cu:33-41 */
+                    const float dnx = dn_base + gx * dn_step, dny = dn_base + gy * dn_step;
+                    const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));
+                    const float wgt = ww * desc_tile[xd] * desc_tile[yd] * mod;
+                    const float tth = mul_up(th, M_4RPI);
+                    const int   fo = (int)floorf(tth);
+                    const float do0 = tth - fo;
+                    dpt[xd][(fo + 1) & 7] = dpt[xd][(fo + 1) & 7] + wgt * do0;
+                    dpt[xd][fo & 7] = dpt[xd][fo & 7] + wgt * (1.0f - do0);
+                }
+            for (int b = 0; b < 8; b++) {
+                float v[16];
+                for (int l = 0; l < 16; l++) v[l] = dpt[l][b];
+                for (int s = 1; s <= 8; s <<= 1) { /* shuffle_xor butterflies: every lane ends with the total */
+                    float t[16];
+                    for (int l = 0; l < 16; l++) t[l] = v[l] + v[l ^ s];
+                    memcpy(v, t, sizeof(v));
+                }
+                features[(((iy << 2) + ix) << 3) + b] = v[0];
+            }
+        }
+}
+
+/* s_desc_iloop.cu:18-133 ext_desc_iloop_sub, block (32,1,16): cell (ix, iy) samples a fixed 32 x 32 lattice
+ * over the bounding box of its rotated two-cell square (lane j = column, 32 rows i), keeps the points with
+ * |n| < 1, interpolated rotated gradient, weights as in the loop descriptor; shuffle_down 16..1. */
+static void descriptor_iloop_one(const oracle_ctx* c, const ext_t* e, float ang, float* features)
+{
+    const oct_t* oc = &c->oct[e->octave];
+    const int    width = oc->w, height = oc->h;
+    const float* layer = oc->data[clampi(e->lpos, 0, c->L - 1)];
+    const float  x = e->xpos, y = e->ypos;
+    const float  SBP = fabsf(DESC_MAGNIFY * e->sigma);
+    const float  M_4RPI = 4.0f / F_PI;
+
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (SBP == 0) return;
+    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+    const float bsz = fabsf(cos_t) + fabsf(sin_t);
+
+    for (int iy = 0; iy < 4; iy++)
+        for (int ix = 0; ix < 4; ix++) {
+            const float offx = ix - 1.5f, offy = iy - 1.5f;
+            const float ptx = fmaf(csbp, offx, -ssbp * offy);
+            const float pty = fmaf(csbp, offy, ssbp * offx);
+            float       dpt[32][9];
+            memset(dpt, 0, sizeof(dpt));
+            for (int j = 0; j < 32; j++) {
+                for (int i = 0; i < 32; i++) {
+                    const float dx = (-bsz + j * bsz / 16.0f);
+                    const float dy = (-bsz + i * bsz / 16.0f);
+                    const float nx = fmaf(cos_t, dx, sin_t * dy);
+                    const float ny = fmaf(cos_t, dy, -sin_t * dx);
+                    const float nnx = fabsf(nx), nny = fabsf(ny);
+                    if (nnx < 1.0f && nny < 1.0f) {
+                        const float jj = x + ptx + dx * SBP;
+                        const float ii = y + pty + dy * SBP;
+                        float       mod, th;
+                        get_gradiant_rot(&mod, &th, jj, ii, cos_t, sin_t, layer, width, height);
+                        const float dnx = nx + offx, dny = ny + offy;
+                        const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));
+                        const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
+                        th += (th < 0.0f ? F_PI2 : 0.0f);
+                        th -= (th >= F_PI2 ? F_PI2 : 0.0f);
+                        const float tth = mul_up(th, M_4RPI);
+                        const int   fo0 = (int)floorf(tth);
+                        const float do0 = tth - fo0;
+                        int         fo = fo0 % 8;
+                        if (fo < 0) fo = 0; /* unreachable for finite input */
+                        dpt[j][fo] = fma_up(1.0f - do0, wgt, dpt[j][fo]);
+                        dpt[j][fo + 1] = fma_up(do0, wgt, dpt[j][fo + 1]);
+                    }
+                }
+                dpt[j][0] += dpt[j][8];
+            }
+            for (int b = 0; b < 8; b++) {
+                float v[32];
+                for (int l = 0; l < 32; l++) v[l] = dpt[l][b];
+                for (int s = 16; s >= 1; s >>= 1)
+                    for (int l = 0; l < s; l++) v[l] += v[l + s];
+                features[(((iy << 2) + ix) << 3) + b] = v[0];
+            }
+        }
+}
+
 /* s_desc_norm_rs.h:44-79 / s_desc_norm_l2.h:87-134 (32 lanes x float4, tree sums) */
 static float tree_sum32(const float* lane)
 {
@@ -1372,6 +1503,10 @@ static int keypoint_stages(oracle_ctx* c)
             float* out = c->desc + 128 * (size_t)(e->idx_ori + k);
             if (c->p.desc_mode == POPSIFT_HIP_DESC_GRID)
                 descriptor_grid_one(c, e, e->orientation[k], raw);
+            else if (c->p.desc_mode == POPSIFT_HIP_DESC_IGRID)
+                descriptor_igrid_one(c, e, e->orientation[k], raw);
+            else if (c->p.desc_mode == POPSIFT_HIP_DESC_ILOOP)
+                descriptor_iloop_one(c, e, e->orientation[k], raw);
             else if (c->p.desc_mode == POPSIFT_HIP_DESC_NOTILE)
                 descriptor_notile_one(c, e, e->orientation[k], raw);
             else

@@ -634,9 +634,7 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
     if (p->levels > POPSIFT_HIP_MAX_LEVELS - 3) return POPSIFT_HIP_ERR_INVALID;
     if (p->gauss_mode != POPSIFT_HIP_GAUSS_VLFEAT_COMPUTE && p->gauss_mode != POPSIFT_HIP_GAUSS_OPENCV_COMPUTE)
         return POPSIFT_HIP_ERR_INVALID;
-    if (p->desc_mode != POPSIFT_HIP_DESC_LOOP && p->desc_mode != POPSIFT_HIP_DESC_GRID &&
-        p->desc_mode != POPSIFT_HIP_DESC_NOTILE)
-        return POPSIFT_HIP_ERR_INVALID;
+    if (p->desc_mode < POPSIFT_HIP_DESC_LOOP || p->desc_mode > POPSIFT_HIP_DESC_NOTILE) return POPSIFT_HIP_ERR_INVALID;
     if (p->sift_mode < 0 || p->sift_mode > 2 || p->norm_mode < 0 || p->norm_mode > 1) return POPSIFT_HIP_ERR_INVALID;
     if (p->max_extrema < 1 || !(p->edge_limit > 0.0f)) return POPSIFT_HIP_ERR_INVALID;
     if (p->filter_max_extrema > 0 &&

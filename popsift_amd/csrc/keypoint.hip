@@ -827,6 +827,7 @@ __device__ __forceinline__ float tex_linear(const float* pl, int w, int h, int p
  * once and spreads it to its <= 2 x 2 cells with the packed fixed-point LDS atomics of the loop
  * kernel.
  */
+template <bool ILOOP>
 __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __restrict__ pdp,
                                                            const float* __restrict__ arena, SiftConsts sc,
                                                            const Counters* __restrict__ ct,
@@ -834,7 +835,8 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
                                                            float* __restrict__ desc, int desc_cap)
 {
     constexpr int    DCOPY = 2;
-    constexpr int    FBITS = 14; /* 256 points per cell, each <= 361 * 1: low halves stay below 2^32 */
+    /* notile: 256 points per cell, iloop: up to 1024, each <= 361 * 1: low halves stay below 2^32 */
+    constexpr int    FBITS = ILOOP ? 13 : 14;
     __shared__ fix64 s_hist[4][DCOPY][128];
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     fix64*           hist = s_hist[wave][lane & (DCOPY - 1)];
@@ -863,6 +865,49 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
         if (sigma != 0.0f) {
             float sin_t, cos_t;
             sincosf(ang, &sin_t, &cos_t);
+            if (ILOOP) {
+                /* DescMode ILoop (s_desc_iloop.cu:18-133): every cell samples a FIXED 32 x 32 lattice over the
+                 * bounding box of its rotated two-cell square and keeps the points inside the square; the
+                 * gradient is the interpolated, rotated one of notile, the weights are the loop descriptor's.
+                 * The reference gives a cell 32 lanes x 32 steps; a wave here takes two lattice rows a step. */
+                const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+                const float bsz = fabsf(cos_t) + fabsf(sin_t);
+                const int   j = lane & 31;
+                for (int cell = 0; cell < 16; cell++) {
+                    const float offx = (float)(cell & 3) - 1.5f, offy = (float)(cell >> 2) - 1.5f;
+                    const float ptx = fmaf(csbp, offx, -ssbp * offy);
+                    const float pty = fmaf(csbp, offy, ssbp * offx);
+                    for (int it = 0; it < 16; it++) {
+                        const int   i = 2 * it + (lane >> 5);
+                        const float dx = -bsz + (float)j * bsz / 16.0f;
+                        const float dy = -bsz + (float)i * bsz / 16.0f;
+                        const float nx = fmaf(cos_t, dx, sin_t * dy);
+                        const float ny = fmaf(cos_t, dy, -sin_t * dx);
+                        const float nnx = fabsf(nx), nny = fabsf(ny);
+                        if (nnx < 1.0f && nny < 1.0f) {
+                            const float px = x + ptx + dx * SBP, py = y + pty + dy * SBP;
+                            const float dxv = tex_linear(layer, width, height, pitch, px + cos_t, py + sin_t) -
+                                              tex_linear(layer, width, height, pitch, px - cos_t, py - sin_t);
+                            const float dyv = tex_linear(layer, width, height, pitch, px - sin_t, py + cos_t) -
+                                              tex_linear(layer, width, height, pitch, px + sin_t, py - cos_t);
+                            const float mod = __builtin_amdgcn_sqrtf(dxv * dxv + dyv * dyv);
+                            float       th = atan2_acc(dyv, dxv);
+                            th += (th < 0.0f ? F_PI2 : 0.0f);
+                            th -= (th >= F_PI2 ? F_PI2 : 0.0f);
+                            const float tth = th * M_4RPI;
+                            const float ffo = floorf(tth);
+                            const float do0 = tth - ffo;
+                            const int   b0 = (int)ffo & 7;
+                            const float dnx = nx + offx, dny = ny + offy;
+                            const float ww = __expf(-0.125f * (dnx * dnx + dny * dny));
+                            const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod * fscale;
+                            const float a1 = do0 * wgt, a0 = wgt - a1;
+                            atomicAdd(&hist[(cell << 3) + b0],
+                                      ((fix64)(unsigned int)(a1 + 0.5f) << 32) | (unsigned int)(a0 + 0.5f));
+                        }
+                    }
+                }
+            } else
             for (int p = lane; p < 1600; p += 64) {
                 const int   newy = p / 40, newx = p - newy * 40;
                 const float stepx = stepbase + 0.125f * (float)newx;
@@ -991,8 +1036,13 @@ int scan_chunk() { return SCAN_CHUNK; }
 hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
                               const Ext* ext, const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
 {
-    if (sc.desc_mode == POPSIFT_HIP_DESC_NOTILE)
-        hipLaunchKernelGGL(k_descriptor_notile, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+    /* IGrid (s_desc_igrid.cu:20-83) evaluates the same 40 x 40 point lattice with the same weights as NoTile,
+     * cell by cell (each point up to four times); the two differ only in summation order (6e-7 relative in the
+     * oracle), so both run the one-evaluation-per-point kernel */
+    if (sc.desc_mode == POPSIFT_HIP_DESC_NOTILE || sc.desc_mode == POPSIFT_HIP_DESC_IGRID)
+        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+    else if (sc.desc_mode == POPSIFT_HIP_DESC_ILOOP)
+        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
         hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
     else

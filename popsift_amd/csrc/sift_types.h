@@ -40,7 +40,7 @@ struct SiftConsts {
     int   max_extrema, norm_multi, norm_mode, sift_mode;
     int   grid_size;
     int   up_fac_int; /* prep_features(Descriptor*, int up_fac): truncated, sift_pyramid.cu:250 */
-    int   desc_mode;  /* POPSIFT_HIP_DESC_LOOP, _GRID or _NOTILE */
+    int   desc_mode;  /* POPSIFT_HIP_DESC_* */
     int   det_qcap;   /* candidate queue entries the fast detection pass may use (tests shrink it) */
     int   filter_max;  /* Config::getFilterMaxExtrema(), <= 0: grid filter off */
     int   filter_mode; /* POPSIFT_HIP_FILTER_* */

@@ -153,9 +153,6 @@ bool PopSift::configure(const popsift::Config& config, bool /*force*/)
     if (_config.getGaussMode() != popsift::Config::VLFeat_Compute &&
         _config.getGaussMode() != popsift::Config::OpenCV_Compute)
         DIE("this build implements the Gauss modes 'vlfeat' and 'opencv' only");
-    if (_config.getDescMode() != popsift::Config::Loop && _config.getDescMode() != popsift::Config::Grid &&
-        _config.getDescMode() != popsift::Config::NoTile)
-        DIE("this build implements the descriptor modes 'loop', 'grid' and 'notile' only");
     if (_config.getScalingMode() != popsift::Config::ScaleDefault) DIE("ScaleDirect is not supported");
     if (_config.getFilterMaxExtrema() > 0 && (_config.getFilterGridSize() < 1 || _config.getFilterGridSize() > 64))
         DIE("the grid filter supports grid sizes 1..64");

@@ -54,7 +54,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu(hip):
     lib = hip.lib()
     h = C.c_void_p()
     assert lib.popsift_hip_ctx_create(0, None, C.byref(h)) == hip.ERR_INVALID
-    for kw in (dict(sigma=2.5), dict(sigma=0.0), dict(levels=10), dict(gauss_mode=1), dict(desc_mode=1), dict(desc_mode=3),
+    for kw in (dict(sigma=2.5), dict(sigma=0.0), dict(levels=10), dict(gauss_mode=1), dict(desc_mode=5), dict(desc_mode=-1),
                dict(sift_mode=7), dict(norm_mode=3), dict(max_extrema=0), dict(edge_limit=0.0)):
         p = hip.default_params(**kw)
         assert lib.popsift_hip_ctx_create(0, C.byref(p), C.byref(h)) == hip.ERR_INVALID, kw

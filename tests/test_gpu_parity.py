@@ -38,6 +38,9 @@ CASES = [
     ("deep_octaves_40x24", dict(octaves=7), (40, 40, 24)),                  # planes shrink to 2x1
     ("tile_edge_257x129_no_upscale", dict(upscale_factor=0.0), (41, 257, 129)),
     ("tall_9x300", dict(), (42, 9, 300)),
+    ("igrid_descriptor", dict(desc_mode=3), (32, 200, 150)),
+    ("iloop_descriptor", dict(desc_mode=1), (33, 200, 150)),
+    ("iloop_descriptor_vlfeat_classic", dict(desc_mode=1, sift_mode=2, norm_mode=1), (34, 160, 120)),
     ("notile_descriptor_opencv_classic", dict(desc_mode=4, sift_mode=1, norm_mode=1, norm_multi=9), (31, 200, 150)),
 ]
 

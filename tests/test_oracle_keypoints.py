@@ -170,3 +170,20 @@ def test_notile_descriptor_mode(oracle_mod):
     cos = np.sum(da * db, axis=1)
     assert np.median(cos) > 0.995 and cos.min() > 0.6
     assert not np.allclose(da, db)
+
+
+def test_interpolated_descriptor_modes(oracle_mod):
+    """DescMode IGrid (s_desc_igrid.cu) evaluates NoTile's point lattice cell by cell: same numbers up to the
+    summation order.  DescMode ILoop (s_desc_iloop.cu) is the loop descriptor's weighting on a fixed 32 x 32
+    lattice per cell with the interpolated gradient: close to Loop, not equal."""
+    O = oracle_mod
+    img = synth(9, 180, 140)
+    res = {m: O.Oracle(O.default_params(desc_mode=m)).run(img).fetch() for m in (0, 1, 3, 4)}
+    for m in (1, 3, 4):
+        assert np.array_equal(res[0][0], res[m][0])                       # keypoints do not depend on the mode
+        np.testing.assert_allclose((res[m][1].astype(np.float64) ** 2).sum(1), 1.0, rtol=2e-4)
+    rel = lambda a, b: np.linalg.norm(a - b, axis=1) / np.linalg.norm(a, axis=1)
+    assert rel(res[4][1], res[3][1]).max() < 1e-5
+    r = rel(res[0][1], res[1][1])
+    cos = np.sum(res[0][1] * res[1][1], axis=1)
+    assert 1e-4 < np.median(r) < 0.05 and np.median(cos) > 0.999 and cos.min() > 0.6

@@ -79,7 +79,7 @@ def test_forced_octaves_and_downsampling(oracle_mod):
 
 def test_rejects_unsupported(oracle_mod):
     O = oracle_mod
-    for kw in (dict(sigma=2.5), dict(levels=10), dict(gauss_mode=1), dict(desc_mode=1), dict(desc_mode=3)):
+    for kw in (dict(sigma=2.5), dict(levels=10), dict(gauss_mode=1), dict(desc_mode=5), dict(desc_mode=-1)):
         with pytest.raises(ValueError):
             O.Oracle(O.default_params(**kw))
 

@@ -292,10 +292,7 @@ struct RowRed {
  * seen outside synthetic stress images; typical is ~50) is handed to the SLOW instantiation of this
  * kernel, which re-does it with a flush per row.
  */
-#ifndef DET_GROUP
-#define DET_GROUP 4
-#endif
-constexpr int DET_G = DET_GROUP;   /* rows per load group */
+constexpr int DET_G = 4;   /* rows per load group (2 and 8, and a double-buffered variant, measured no better) */
 constexpr int DET_Q = 512; /* per-wave candidate queue (entries) */
 
 template <int MODE, int LEVELS, bool SLOW>
@@ -440,22 +437,6 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             }
             flush(n_buf);
         } else {
-#ifdef DET_PIPE
-            /* two register buffers: the loads of the next group are in flight while a group is consumed */
-            float q0[DET_G][3 * NP], q1[DET_G][3 * NP];
-#pragma unroll
-            for (int k = 0; k < DET_G; k++) fetch_row(min(yb + k + 1, ye + 1), q0[k]);
-            for (int y0 = yb; y0 <= ye; y0 += 2 * DET_G) {
-#pragma unroll
-                for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + DET_G + k + 1, ye + 1), q1[k]);
-#pragma unroll
-                for (int k = 0; k < DET_G; k++) step(y0 + k, q0[k]);
-#pragma unroll
-                for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + 2 * DET_G + k + 1, ye + 1), q0[k]);
-#pragma unroll
-                for (int k = 0; k < DET_G; k++) step(y0 + DET_G + k, q1[k]); /* rows past ye cannot hit */
-            }
-#else
             for (int y0 = yb; y0 <= ye; y0 += DET_G) {
                 float q[DET_G][3 * NP];
 #pragma unroll
@@ -463,7 +444,6 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) step(y0 + k, q[k]);
             }
-#endif
             if (overflow) {
                 /* too many candidates for the queue: leave the whole strip to the SLOW pass */
                 if (lane == 0) ovf[atomicAdd(&ct->pad[1], 1)] = unit;

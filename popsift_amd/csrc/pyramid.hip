@@ -322,8 +322,12 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                 const int gy = ty0 + r0 + o;
                 if (gx < w && gy < h) {
                     /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */
+                    /* the Gaussian plane is the next level's input (keep it cached); the DoG plane is not touched again
+                     * before the detection kernel: a non-temporal store keeps it from evicting the plane
+                     * (measured: level launches -4 %, detection -7 %; non-temporal for both: levels +20 %) */
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
-                    if (MODE == 0) *reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]) = acc - old[g][o];
+                    if (MODE == 0)
+                        __builtin_nontemporal_store(acc - old[g][o], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
                 }
             }
         }

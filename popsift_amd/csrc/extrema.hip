@@ -8,8 +8,9 @@
  *
  * Differences by design: planes are plain HBM rows (coalesced 256 B per wave
  * row, clamp done in software, neighbours served by L1/L2), the compaction is
- * a 64-bit __ballot + one atomicAdd per wave (the reference's 32-bit lane
- * masks are wrong on wave64), and the per-octave counter is clamped to
+ * a 64-bit __ballot into a per-wave LDS queue + one atomicAdd per strip into one
+ * of 64 sub-queues (the reference's 32-bit lane masks are wrong on wave64, and a
+ * single hot counter saturates), and the per-octave counter is clamped to
  * max_extrema by its consumers instead of by a "last block" epilogue.
  * The refinement arithmetic follows the reference expression by expression
  * (compiled with -ffp-contract=off) so that, given identical DoG planes, the
@@ -250,29 +251,15 @@ __device__ bool refine(const DogView& dog, const SiftConsts& sc, int x, int y, i
 }
 
 /*
- * Detection: every DoG value is read exactly once.  One wave owns a strip of 62
- * candidate columns (lanes 1..62; lanes 0 and 63 only supply neighbours) and
- * marches down DET_RH rows.  For each of the 5 planes a row is reduced to
- * max3/min3 over (left, self, right) with two lane shifts; three consecutive
- * rows of these give the 3x3 neighbourhood extremes of the planes above and
- * below, and (with the centre excluded) of the own plane -- the strict 26-
- * neighbour test of s_extrema.cu:56-120 without any divergent load.
+ * Detection: one wave owns a strip of 64 candidate columns and marches down DET_RH rows.  Per plane a row
+ * is three overlapping row loads (left neighbour, self, right neighbour: the same cache lines), reduced to
+ * max3/min3; three consecutive rows of these give the 3x3 neighbourhood extremes of the planes above and
+ * below, and (with the centre excluded) of the own plane -- the strict 26-neighbour test of
+ * s_extrema.cu:56-120 without any divergent load.  (A first version shifted lanes with wave-wide DPP
+ * instead of loading the neighbours; those shifts stalled the wave for tens of cycles each on gfx950.)
  */
 constexpr int DET_W = 64;
 constexpr int DET_RH = 32;
-
-/* neighbour lane values through DPP wave shifts (VALU rate) instead of ds_bpermute (LDS
- * crossbar); lanes 0 / 63 have no source and keep their own value, like __shfl_up/_down */
-__device__ __forceinline__ float lane_left(float v)
-{
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_right(float v)
-{
-    const int i = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
 
 template <int NP>
 struct RowRed {

@@ -1,16 +1,19 @@
 /*
- * keypoint.hip -- orientation assignment, orientation prefix sum, 128-D "loop"
- * descriptor + normalisation, Feature assembly.  All kernels size themselves
+ * keypoint.hip -- orientation assignment, orientation prefix sum, the 128-D descriptors
+ * (loop, grid, notile / igrid, iloop) + normalisation, Feature assembly.  All kernels size themselves
  * from the device-resident counters (grid-stride), so the host never has to
  * read a count back between stages (the reference blocks on the counters twice
  * per image: s_orientation.cu:351, sift_desc.cu:60-61).
  *
  * Replaces:
  *   ori_par               s_orientation.cu:60-242   -> k_orientation (1 wave / extremum)
- *   ori_prefix_sum        s_orientation.cu:303-345  -> k_scan (1 workgroup, wave64 scans)
- *   ext_desc_loop(+_sub)  s_desc_loop.cu:19-161     -> k_descriptor (1 workgroup / descriptor)
+ *   ori_prefix_sum        s_orientation.cu:303-345  -> k_scan_local + k_scan_apply (2048 extrema / workgroup)
+ *   ext_desc_loop(+_sub)  s_desc_loop.cu:19-161     -> k_descriptor (1 wave / descriptor)
+ *   ext_desc_grid         s_desc_grid.cu:19-147     -> k_descriptor_grid
+ *   ext_desc_notile/igrid s_desc_notile.cu:28-166, s_desc_igrid.cu:20-109 -> k_descriptor_notile<false>
+ *   ext_desc_iloop        s_desc_iloop.cu:18-154    -> k_descriptor_notile<true>
  *   normalize_histogram   s_desc_normalize.h:14-33, s_desc_norm_rs.h, s_desc_norm_l2.h
- *                                                   -> fused into k_descriptor
+ *                                                   -> fused into the descriptor kernels
  *   prep_features         sift_pyramid.cu:249-279   -> k_prep
  */
 #include <hip/hip_runtime.h>

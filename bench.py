@@ -5,9 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU.  A "step" is one pass of the extraction hot path over one
-batch of --batch synthetic images per GPU (inputs already resident in HBM, one
-extraction context + HIP stream per in-flight image, results left device
-resident like the reference's FeaturesDev).  Images are independent, so ranks
+batch of --batch synthetic images per GPU (inputs already resident in HBM;
+--contexts extraction contexts, each with its own HIP stream, work through the
+batch with one image in flight per context; results left device resident like
+the reference's FeaturesDev).  Images are independent, so ranks
 never talk on the data path (weak scaling, no RCCL); torch.distributed is used
 for the barriers around the timed region and the MAX over ranks only.
 
@@ -37,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="images per step per GPU (one step = one batch)")
+    ap.add_argument("--contexts", type=int, default=16, help="extraction contexts (images in flight) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context roofline pass (the command profiles/ *_roofline_pass* was taken with)")
@@ -56,22 +58,47 @@ def blur_traffic():
         return None
 
 
-def run_step(ctxs, ptrs, pool):
-    """Submit one image per context, then wait for all of them."""
-    def work(i):
-        ctxs[i].submit_dev(ptrs[i], W, H, W)
-        ctxs[i].wait()
-    if pool is None:
-        for i in range(len(ctxs)):
-            ctxs[i].submit_dev(ptrs[i], W, H, W)
-        for c in ctxs:
-            c.wait()
-        return
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+class Workers:
+    """One persistent thread per extraction context.  A step hands every context its share of the batch
+    (images i, i + C, i + 2C, ... of the step), which the context extracts back to back; the step ends when
+    every context has finished its last image."""
+
+    def __init__(self, ctxs, ptrs):
+        self.ctxs, self.ptrs = ctxs, ptrs
+        self.n = len(ctxs)
+        self.go = threading.Barrier(self.n + 1)
+        self.done = threading.Barrier(self.n + 1)
+        self.stop = False
+        self.feats = [0] * self.n
+        self.descs = [0] * self.n
+        self.threads = [threading.Thread(target=self._loop, args=(i,), daemon=True) for i in range(self.n)]
+        for t in self.threads:
+            t.start()
+
+    def _loop(self, i):
+        ctx = self.ctxs[i]
+        while True:
+            self.go.wait()
+            if self.stop:
+                return
+            f = d = 0
+            for p in self.ptrs[i::self.n]:
+                ctx.submit_dev(p, W, H, W)
+                nf, nd = ctx.wait()
+                f += nf
+                d += nd
+            self.feats[i], self.descs[i] = f, d
+            self.done.wait()
+
+    def step(self):
+        self.go.wait()
+        self.done.wait()
+
+    def close(self):
+        self.stop = True
+        self.go.wait()
+        for t in self.threads:
+            t.join()
 
 
 ROOT = HERE
@@ -110,12 +137,14 @@ def main():
 
     B = 1 if args.only_roofline else args.batch
     # config 4 seeds 100.. for batches; config 2's own image (seed 2) is image 0 of rank 0
-    seeds = [2 if (rank == 0 and i == 0) else 100 + rank * B + i for i in range(B)]
+    U = min(B, 16)  # distinct images per rank (0.5 s of host time each to synthesise); the batch cycles through them
+    seeds = [2 if (rank == 0 and i == 0) else 100 + rank * U + i for i in range(U)]
     host_imgs = [synth(s, W, H) for s in seeds]
     dev_imgs = [torch.from_numpy(im).cuda(local_rank) for im in host_imgs]  # inputs resident in HBM
-    ptrs = [t.data_ptr() for t in dev_imgs]
-    ctxs = [hip.Context(hip.default_params(), device=local_rank) for _ in range(B)]
-    pool = True if B > 1 else None
+    ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
+    C = max(1, min(args.contexts, B))
+    ctxs = [hip.Context(hip.default_params(), device=local_rank) for _ in range(C)]
+    workers = Workers(ctxs, ptrs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -125,17 +154,18 @@ def main():
     if args.only_roofline:
         args.steps, args.warmup = 1, 0
     for _ in range(args.warmup):
-        run_step(ctxs, ptrs, pool)
+        workers.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step(ctxs, ptrs, pool)
+        workers.step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    workers.close()
 
-    feats = sum(c.report().ext_total for c in ctxs)
-    descs = sum(c.report().ori_total for c in ctxs)
+    feats = sum(workers.feats)   # of one step
+    descs = sum(workers.descs)
     rdev = "cuda" if backend == "nccl" else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     cnt = torch.tensor([feats, descs], dtype=torch.float64, device=rdev)
@@ -240,7 +270,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "1920x1080 u8 grayscale, default popsift::Config (2x upscale, 9 octaves, "
                                    "3 levels, PopSift mode, loop descriptor, RootSift)",
-                       "images_per_step_per_gpu": B, "in_flight_contexts_per_gpu": B,
+                       "images_per_step_per_gpu": B, "distinct_images_per_gpu": U, "in_flight_contexts_per_gpu": C,
                        "results": "device resident (features + descriptors)"},
             "features_per_s": round(feats_step * args.steps / elapsed, 1),
             "descriptors_per_s": round(descs_step * args.steps / elapsed, 1),

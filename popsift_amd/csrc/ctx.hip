@@ -819,6 +819,9 @@ int popsift_hip_devfeatures_free(popsift_hip_devfeatures* f)
     if (f->m_partial) (void)hipFree(f->m_partial);
     if (f->m_out) (void)hipFree(f->m_out);
     if (f->m_host) (void)hipHostFree(f->m_host);
+    if (f->m_redo) (void)hipFree(f->m_redo);
+    if (f->d_norm) (void)hipFree(f->d_norm);
+    if (f->m_rnorm) (void)hipFree(f->m_rnorm);
     delete f;
     return POPSIFT_HIP_OK;
 }
@@ -931,8 +934,21 @@ int popsift_hip_match_sets(const popsift_hip_devfeatures* lc, const popsift_hip_
     }
     if (rc == POPSIFT_HIP_OK && !l->m_out) ok(hipMalloc(&l->m_out, out_bytes));
     if (rc == POPSIFT_HIP_OK && !l->m_host) ok(hipHostMalloc(&l->m_host, out_bytes, hipHostMallocDefault));
-    const int    n_split = match_splits(l->n_desc, r->n_desc);
-    const size_t need = match_partial_bytes(l->n_desc, n_split);
+    /* large problems: matrix-core screening + exact re-rank (match_mfma.hip); small ones and
+     * POPSIFT_HIP_MATCH_EXACT=1: the exact brute-force kernel alone (match.hip) */
+    const char*  e_exact = getenv("POPSIFT_HIP_MATCH_EXACT");      /* read per call: tests switch paths */
+    const char*  e_min = getenv("POPSIFT_HIP_MATCH_SCREEN_MIN");  /* pairs from which screening pays */
+    const double min_pairs = e_min ? atof(e_min) : 4.0e6;
+    const bool   screen = !(e_exact && atoi(e_exact) != 0) && (double)l->n_desc * (double)r->n_desc >= min_pairs;
+    const int         n_split = match_splits(l->n_desc, r->n_desc);
+    const int         s_split = screen ? screen_splits(l->n_desc, r->n_desc) : 1;
+    /* rows the screening pass cannot decide are few: the first REDO_CAP of them are matched with the right set split
+     * over many workgroups, a second launch (normally empty) covers the rest of the list */
+    const int    REDO_CAP = 2048;
+    const int    redo_split = std::min(256, std::max((r->n_desc + 63) / 64, 1));
+    size_t       need = match_partial_bytes(l->n_desc, n_split);
+    if (screen) need = std::max(need, screen_partial_bytes(l->n_desc, s_split));
+    if (screen) need = std::max(need, match_partial_bytes(REDO_CAP, redo_split));
     if (rc == POPSIFT_HIP_OK && need > l->m_partial_cap) {
         if (l->m_partial) (void)hipFree(l->m_partial);
         l->m_partial = nullptr;
@@ -946,10 +962,40 @@ int popsift_hip_match_sets(const popsift_hip_devfeatures* lc, const popsift_hip_
             rdesc = r_copy;
     }
     hipStream_t s = (hipStream_t)l->m_stream;
-    if (rc == POPSIFT_HIP_OK &&
-        ok(launch_match(l->d_desc, l->n_desc, rdesc, r->n_desc, n_split, l->m_partial, (popsift_hip_match*)l->m_out, s)) &&
-        ok(hipMemcpyAsync(l->m_host, l->m_out, out_bytes, hipMemcpyDeviceToHost, s)) && ok(hipStreamSynchronize(s)))
+    float*      rnorm = nullptr;
+    if (rc == POPSIFT_HIP_OK && screen) {
+        if (!l->m_redo) ok(hipMalloc((void**)&l->m_redo, sizeof(int) * ((size_t)l->n_desc + 1)));
+        if (rc == POPSIFT_HIP_OK && !l->d_norm && ok(hipMalloc((void**)&l->d_norm, sizeof(float) * (size_t)l->n_desc)))
+            ok(launch_norms(l->d_desc, l->n_desc, l->d_norm, s));
+        /* the right set may be the left set of another thread's match: its norms go to a buffer of this call */
+        if (rc == POPSIFT_HIP_OK && (size_t)r->n_desc > l->m_rnorm_cap) {
+            if (l->m_rnorm) (void)hipFree(l->m_rnorm);
+            l->m_rnorm = nullptr;
+            l->m_rnorm_cap = 0;
+            if (ok(hipMalloc((void**)&l->m_rnorm, sizeof(float) * (size_t)r->n_desc))) l->m_rnorm_cap = (size_t)r->n_desc;
+        }
+        rnorm = l->m_rnorm;
+        if (rc == POPSIFT_HIP_OK) ok(launch_norms(rdesc, r->n_desc, rnorm, s));
+    }
+    if (rc == POPSIFT_HIP_OK && screen) {
+        ok(launch_match_screen(l->d_desc, l->n_desc, rdesc, r->n_desc, l->d_norm, rnorm, s_split, l->m_partial,
+                               (popsift_hip_match*)l->m_out, l->m_redo + 1, l->m_redo, s)) &&
+            ok(launch_match(l->d_desc, l->n_desc, rdesc, r->n_desc, redo_split, l->m_partial, (popsift_hip_match*)l->m_out,
+                            l->m_redo + 1, l->m_redo, 0, REDO_CAP, s)) &&
+            ok(launch_match(l->d_desc, l->n_desc, rdesc, r->n_desc, n_split, l->m_partial, (popsift_hip_match*)l->m_out,
+                            l->m_redo + 1, l->m_redo, REDO_CAP, l->n_desc, s));
+    } else if (rc == POPSIFT_HIP_OK) {
+        ok(launch_match(l->d_desc, l->n_desc, rdesc, r->n_desc, n_split, l->m_partial, (popsift_hip_match*)l->m_out, nullptr,
+                        nullptr, 0, 0, s));
+    }
+    if (rc == POPSIFT_HIP_OK && ok(hipMemcpyAsync(l->m_host, l->m_out, out_bytes, hipMemcpyDeviceToHost, s)) &&
+        ok(hipStreamSynchronize(s)))
         memcpy(out, l->m_host, out_bytes);
+    if (rc == POPSIFT_HIP_OK && screen && getenv("POPSIFT_HIP_MATCH_DEBUG")) {
+        int redo = 0;
+        (void)hipMemcpy(&redo, l->m_redo, sizeof(int), hipMemcpyDeviceToHost);
+        fprintf(stderr, "popsift_hip_match_sets: %d x %d, %d rows left to the exact kernel\n", l->n_desc, r->n_desc, redo);
+    }
     if (r_copy) (void)hipFree(r_copy);
     return rc;
 }

@@ -26,4 +26,8 @@ struct popsift_hip_devfeatures {
     size_t m_partial_cap = 0;
     void*  m_out = nullptr;     /* popsift_hip_match[n_desc] */
     void*  m_host = nullptr;    /* pinned staging of the same size */
+    int*   m_redo = nullptr;    /* [0] = count, [1 ..] = rows the screening pass left to the exact kernel */
+    float* d_norm = nullptr;    /* |x|^2 per descriptor, computed on first use by a match */
+    float* m_rnorm = nullptr;   /* norms of the right set of the current call */
+    size_t m_rnorm_cap = 0;
 };

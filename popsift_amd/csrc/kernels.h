@@ -56,7 +56,15 @@ hipError_t launch_filter(int n_oct, const SiftConsts& sc, Counters* ct, const In
 int        match_splits(int l_len, int r_len);
 size_t     match_partial_bytes(int l_len, int n_split);
 hipError_t launch_match(const float* ldesc, int l_len, const float* rdesc, int r_len, int n_split, void* partial,
-                        popsift_hip_match* out, hipStream_t s);
+                        popsift_hip_match* out, const int* rows, const int* n_rows, int first_row, int row_end,
+                        hipStream_t s);
+/* match_mfma.hip: matrix-core screening + exact re-rank of the survivors */
+int        screen_splits(int l_len, int r_len);
+size_t     screen_partial_bytes(int l_len, int n_split);
+hipError_t launch_norms(const float* desc, int n, float* out, hipStream_t s);
+hipError_t launch_match_screen(const float* ldesc, int l_len, const float* rdesc, int r_len, const float* lnorm,
+                               const float* rnorm, int n_split, void* partial, popsift_hip_match* out, int* redo_list,
+                               int* redo_count, hipStream_t s);
 /* Feature records (72-byte popsift::Feature layout) with device descriptor pointers for a cloned set */
 hipError_t launch_clone_features(const popsift_hip_feature* feats, int n_feat, float* desc_base, void* out, hipStream_t s);
 

@@ -121,19 +121,24 @@ __device__ __forceinline__ Acc pair_distances(const float* __restrict__ lrow, co
  */
 __global__ __launch_bounds__(256, 2) void k_match(const float* __restrict__ ldesc, int l_len,
                                                const float* __restrict__ rdesc, int r_len, int n_split,
-                                               Top2* __restrict__ partial)
+                                               Top2* __restrict__ partial, const int* __restrict__ rows,
+                                               const int* __restrict__ n_rows, int first_row, int row_end)
 {
+    /* rows != null: only the left descriptors rows[first_row .. min(*n_rows, row_end)) -- the list the screening
+     * pass could not decide; positions in that list index `partial` */
+    if (rows) l_len = min(min(*n_rows, row_end), l_len);
+    if (first_row + (int)blockIdx.x * M_LT >= l_len) return; /* whole workgroup, before any barrier */
     __shared__ float s_l[M_LT * M_ROW];
     __shared__ float s_r[M_RT * M_ROW];
     const int        tid = threadIdx.x;
     const int        lg = tid >> 5, rg = tid & 31; /* lane's left rows 4*lg.., right rows 2*rg.. */
-    const int        l0 = blockIdx.x * M_LT;
+    const int        l0 = first_row + blockIdx.x * M_LT;
 
     /* left tile, zero rows past the end */
     for (int c = tid; c < M_LT * 32; c += 256) {
         const int row = c >> 5, ch = c & 31;
         v4f       v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (l0 + row < l_len) v = *(const v4f*)(ldesc + (size_t)(l0 + row) * 128 + 4 * ch);
+        if (l0 + row < l_len) v = *(const v4f*)(ldesc + (size_t)(rows ? rows[l0 + row] : l0 + row) * 128 + 4 * ch);
         *(v4f*)(s_l + row * M_ROW + 4 * ch) = v;
     }
 
@@ -195,9 +200,11 @@ __global__ __launch_bounds__(256, 2) void k_match(const float* __restrict__ ldes
 
 /* merge the per-split candidates; accept as in features.cu:217-218 */
 __global__ __launch_bounds__(256) void k_match_finish(const Top2* __restrict__ partial, int l_len, int n_split,
-                                                      popsift_hip_match* __restrict__ out)
+                                                      popsift_hip_match* __restrict__ out, const int* __restrict__ rows,
+                                                      const int* __restrict__ n_rows, int first_row, int row_end)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = first_row + blockIdx.x * 256 + threadIdx.x;
+    if (rows) l_len = min(min(*n_rows, row_end), l_len);
     if (l >= l_len) return;
     Top2 t = partial[(size_t)l * n_split];
     for (int k = 1; k < n_split; k++) {
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void k_match_finish(const Top2* __restrict__ p
     m.accept = (__fdiv_rn(t.v1, t.v2) < 0.8f) ? 1 : 0;
     m.dist_best = t.v1;
     m.dist_second = t.v2;
-    out[l] = m;
+    out[rows ? rows[l] : l] = m;
 }
 
 /* prep_features writing into a FeaturesDev (sift_pyramid.cu:323-345): indices -> device pointers */
@@ -256,13 +263,19 @@ int match_splits(int l_len, int r_len)
 }
 
 hipError_t launch_match(const float* ldesc, int l_len, const float* rdesc, int r_len, int n_split, void* partial,
-                        popsift_hip_match* out, hipStream_t s)
+                        popsift_hip_match* out, const int* rows, const int* n_rows, int first_row, int row_end,
+                        hipStream_t s)
 {
-    if (l_len <= 0) return hipSuccess;
-    const int l_blocks = (l_len + M_LT - 1) / M_LT;
-    hipLaunchKernelGGL(k_match, dim3(l_blocks, n_split), dim3(256), 0, s, ldesc, l_len, rdesc, r_len, n_split,
-                       (Top2*)partial);
-    hipLaunchKernelGGL(k_match_finish, dim3((l_len + 255) / 256), dim3(256), 0, s, (const Top2*)partial, l_len, n_split, out);
+    /* without a row list: all of [0, l_len).  With one: list positions [first_row, row_end); the launch is sized for
+     * that range and workgroups past the device-side count leave at once */
+    const int begin = rows ? first_row : 0;
+    const int end = rows ? std::min(row_end, l_len) : l_len;
+    if (end <= begin) return hipSuccess;
+    const int cover = end - begin;
+    hipLaunchKernelGGL(k_match, dim3((cover + M_LT - 1) / M_LT, n_split), dim3(256), 0, s, ldesc, l_len, rdesc, r_len, n_split,
+                       (Top2*)partial, rows, n_rows, begin, end);
+    hipLaunchKernelGGL(k_match_finish, dim3((cover + 255) / 256), dim3(256), 0, s, (const Top2*)partial, l_len, n_split, out,
+                       rows, n_rows, begin, end);
     return hipGetLastError();
 }
 

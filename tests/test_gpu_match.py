@@ -80,3 +80,46 @@ def test_full_size_sets(oracle_mod, gpu_hip):
     d = ((da[idx].astype(np.float64) - db[m["best"][idx]]) ** 2).sum(-1)
     np.testing.assert_allclose(m["dist_best"][idx], d, rtol=1e-5)
     assert np.all(m["dist_best"] <= m["dist_second"])
+
+
+@pytest.mark.parametrize("nl,nr", [(1, 1), (2, 3), (5, 4), (33, 5), (130, 129), (257, 1000), (1500, 2100)])
+def test_screened_path_matches_the_oracle(oracle_mod, gpu_hip, monkeypatch, nl, nr):
+    """Matrix-core screening + exact re-rank (match_mfma.hip) forced for every size, against the oracle."""
+    monkeypatch.setenv("POPSIFT_HIP_MATCH_SCREEN_MIN", "0")
+    rng = np.random.default_rng(nl * 31 + nr)
+    l = rng.random((nl, 128), np.float32)
+    l /= np.linalg.norm(l, axis=1, keepdims=True)
+    r = rng.random((nr, 128), np.float32)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    k = min(nl, nr) // 2
+    r[rng.permutation(nr)[:k]] = l[rng.permutation(nl)[:k]] + rng.normal(0, 0.01, (k, 128)).astype(np.float32)
+    L, R = gpu_hip.DevFeatures.from_host(l), gpu_hip.DevFeatures.from_host(r)
+    assert_same(oracle_mod.match(l, r), L.match(R))
+
+
+def test_screening_margin_cases(oracle_mod, gpu_hip, monkeypatch):
+    """Rows the screening pass cannot decide -- exact duplicates and near-ties in the right set, more of them than
+    it tracks -- go to the exact kernel; large norms (norm_multi) scale the margin."""
+    monkeypatch.setenv("POPSIFT_HIP_MATCH_SCREEN_MIN", "0")
+    rng = np.random.default_rng(7)
+    l = rng.random((300, 128), np.float32)
+    r = rng.random((900, 128), np.float32)
+    r[10:17] = l[5]                                        # seven exact copies of a left row: all distance 0
+    r[100:106] = l[6] + 1e-7                               # six near-copies inside the margin
+    r[200] = l[7]
+    r[201] = l[7] + np.float32(3e-4)                       # best and second a hair apart
+    r[300:303] = r[299]                                    # duplicates that are nobody's neighbour
+    for scale in (1.0, 512.0):
+        ls, rs = (l * scale).astype(np.float32), (r * scale).astype(np.float32)
+        L, R = gpu_hip.DevFeatures.from_host(ls), gpu_hip.DevFeatures.from_host(rs)
+        m = L.match(R)
+        assert_same(oracle_mod.match(ls, rs), m)
+        assert m["best"][5] == 10 and m["second"][5] == 11 and m["best"][7] == 200
+    # and the two paths agree with each other on a bigger case
+    l = rng.random((3000, 128), np.float32)
+    r = rng.random((5000, 128), np.float32)
+    L, R = gpu_hip.DevFeatures.from_host(l), gpu_hip.DevFeatures.from_host(r)
+    a = L.match(R)
+    monkeypatch.setenv("POPSIFT_HIP_MATCH_EXACT", "1")
+    b = L.match(R)
+    assert_same(a, b)

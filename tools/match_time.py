@@ -20,3 +20,16 @@ for nl, nr in SIZES:
     pairs = nl * nr
     print("match %6d x %6d: %8.3f ms  %7.1f Gpairs/s  %6.1f TFLOP/s (3 flop x 128 per pair)  accept %.3f" % (
         nl, nr, t * 1e3, pairs / t / 1e9, pairs * 384 / t / 1e12, m["accept"].mean()), flush=True)
+
+# real descriptors: two unrelated 1080p synthetic images (no true correspondences: the hardest case for screening)
+from popsift_amd.synth import synth
+a = hip.Context().submit(synth(2, 1920, 1080))
+b = hip.Context().submit(synth(102, 1920, 1080))
+A, B = a.clone_results(), b.clone_results()
+A.match(B)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); m = A.match(B); ts.append(time.perf_counter() - t0)
+nl, nr = A.info()[2], B.info()[2]
+print("match %6d x %6d SIFT descriptors of two images: %8.3f ms  %7.1f Gpairs/s  accept %.3f" % (
+    nl, nr, min(ts) * 1e3, nl * nr / min(ts) / 1e9, m["accept"].mean()), flush=True)

@@ -120,11 +120,21 @@ __global__ __launch_bounds__(256, 2) void k_match_screen(const float* __restrict
     for (int tile = blockIdx.y; tile < n_tiles; tile += n_split) {
         const int r0 = tile * S_RB;
         __syncthreads(); /* previous tile consumed */
-        for (int c = tid; c < S_RB * 32; c += 256) {
-            const int row = c >> 5, ch = c & 31;
-            v4f       v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r0 + row < r_len) v = *(const v4f*)(rdesc + (size_t)(r0 + row) * 128 + 4 * ch);
-            *(v4f*)(s_r + row * S_ROW + 4 * ch) = v;
+        {
+            /* all 16 loads of a lane in flight before the first LDS store (unconditional: rows past the end are
+             * clamped and zeroed afterwards -- a load under a condition makes the compiler wait for each one) */
+            v4f st[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int c = tid + 256 * k, row = c >> 5, ch = c & 31;
+                st[k] = *(const v4f*)(rdesc + (size_t)min(r0 + row, r_len - 1) * 128 + 4 * ch);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int c = tid + 256 * k, row = c >> 5, ch = c & 31;
+                if (r0 + row >= r_len) st[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                *(v4f*)(s_r + row * S_ROW + 4 * ch) = st[k];
+            }
         }
         if (tid < S_RB) s_rn[tid] = (r0 + tid < r_len) ? rnorm[r0 + tid] : INFINITY;
         __syncthreads();

@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256, 2) void k_match(const float* __restrict__ ldes
         for (int k = 0; k < 8; k++) {
             const int c = tid + 256 * k, row = c >> 5, ch = c & 31;
             const int r = tile * M_RT + row;
-            v4f       v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r < r_len) v = *(const v4f*)(rdesc + (size_t)r * 128 + 4 * ch);
-            stage[k] = v;
+            /* unconditional (clamped) loads: a load under a condition is waited for one by one; rows past the end
+             * are never inserted (their index test fails), so their values do not matter */
+            stage[k] = *(const v4f*)(rdesc + (size_t)min(r, r_len - 1) * 128 + 4 * ch);
         }
     };
     int tile = blockIdx.y;

@@ -184,6 +184,19 @@ def test_match_program(gpu_hip, oracle_mod, tmp_path):
     assert sum(1 for g in got if g[0] == "accept") > len(got) // 4
 
 
+@pytest.mark.gpu
+def test_concurrent_callers_and_two_objects(gpu_hip):
+    """tests/cpp/host_mt_test.cpp: four caller threads into one PopSift object, a MatchingMode object alongside."""
+    _build_host()
+    exe = os.path.join(ROOT, "tests", "cpp", "host_mt_test.bin")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_mt_test.cpp"), "-o", exe, "-L", PKG,
+                           "-lpopsift", "-lpopsift_hip", "-pthread", "-Wl,-rpath," + PKG])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "host_mt_test ok" in r.stdout
+
+
 def test_demo_command_line_errors():
     _build_host()
     r = subprocess.run([DEMO, "--help"], capture_output=True, text=True)

@@ -101,6 +101,8 @@ private:
         std::thread      thread;
         popsift_hip_ctx* ctx = nullptr;
         int              device = 0;
+        void*            pod = nullptr; /* pinned staging for the POD features of a download */
+        size_t           pod_cap = 0;
     };
 
     void start_workers(int w, int h);

@@ -216,14 +216,21 @@ void PopSift::worker_loop(Worker* me)
         popsift::FeaturesHost* features = new popsift::FeaturesHost(nf, nd);
         if (nd == 0) cerr << "Warning: no descriptors extracted" << endl; /* sift_desc.cu:88-92 */
         if (nf > 0) {
-            std::vector<popsift_hip_feature> pod((size_t)nf);
-            rc = popsift_hip_fetch(me->ctx, pod.data(), pod.size(), (float*)features->getDescriptors(),
-                                   (size_t)nd * 128);
+            /* the POD features land in a pinned buffer of this worker (a pageable target would be staged by the
+             * runtime at a fraction of the PCIe rate), the descriptors directly in the caller-visible pinned block */
+            if ((size_t)nf > me->pod_cap) {
+                popsift_hip_host_free(me->pod);
+                me->pod_cap = (size_t)nf + (size_t)nf / 4 + 1024;
+                me->pod = popsift_hip_host_alloc(me->pod_cap * sizeof(popsift_hip_feature));
+                if (!me->pod) DIE("Memory limitation: failed to allocate the feature staging buffer");
+            }
+            popsift_hip_feature* pod = (popsift_hip_feature*)me->pod;
+            rc = popsift_hip_fetch(me->ctx, pod, me->pod_cap, (float*)features->getDescriptors(), (size_t)nd * 128);
             if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
             popsift::Feature*    out = features->getFeatures();
             popsift::Descriptor* base = features->getDescriptors();
             for (int i = 0; i < nf; i++) {
-                const popsift_hip_feature& s = pod[(size_t)i];
+                const popsift_hip_feature& s = pod[i];
                 popsift::Feature&          f = out[i];
                 f.debug_octave = s.debug_octave;
                 f.xpos = s.xpos;
@@ -260,6 +267,7 @@ void PopSift::uninit()
     for (Worker* wk : _workers) {
         if (wk->thread.joinable()) wk->thread.join();
         popsift_hip_ctx_destroy(wk->ctx);
+        popsift_hip_host_free(wk->pod);
         delete wk;
     }
     _workers.clear();

@@ -854,6 +854,16 @@ static void orientation_one(const oracle_ctx* c, ext_t* e)
 
 /* ------------------------------------------------------------- descriptor */
 
+/* cos / sin of the keypoint orientation (the reference: __sincosf, a fast intrinsic of a few ulp).  Evaluated in
+ * double and rounded once, i.e. correctly rounded floats up to a ~1e-8 chance of double rounding: the HIP kernels
+ * do the same, so both sides rotate the sampling frame by the SAME two floats -- with the single-precision libm
+ * functions host and device differed by an ulp now and then, which the pixel-snapping grid descriptor amplifies. */
+static inline void sincos_cr(float ang, float* s, float* c)
+{
+    *s = (float)sin((double)ang);
+    *c = (float)cos((double)ang);
+}
+
 /* __fmaf_ru / __fmul_ru (round towards +inf), computed exactly without touching
  * the FP environment: the product of two floats is exact in double; TwoSum
  * gives the exact error of the double addition. */
@@ -888,7 +898,8 @@ static void descriptor_one(const oracle_ctx* c, const ext_t* e, float ang, float
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (SBP == 0) return;
 
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    float cos_t, sin_t;
+    sincos_cr(ang, &sin_t, &cos_t);
     const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
     const float crsbp = cos_t / SBP, srsbp = sin_t / SBP;
 
@@ -974,7 +985,8 @@ static void descriptor_grid_one(const oracle_ctx* c, const ext_t* e, float ang, 
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (SBP == 0) return;
 
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    float cos_t, sin_t;
+    sincos_cr(ang, &sin_t, &cos_t);
     const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
 
     for (int iy = 0; iy < 4; iy++)
@@ -1069,7 +1081,8 @@ static void descriptor_notile_one(const oracle_ctx* c, const ext_t* e, float ang
 
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (e->sigma == 0) return;
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    float cos_t, sin_t;
+    sincos_cr(ang, &sin_t, &cos_t);
 
     float desc_tile[16];
     for (int i = 0; i < 16; i++) desc_tile[i] = 1.0f - fabsf(-1.0f + 1.0f / 16.0f + i * 1.0f / 8.0f);
@@ -1148,7 +1161,8 @@ static void descriptor_igrid_one(const oracle_ctx* c, const ext_t* e, float ang,
 
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (e->sigma == 0) return;
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    float cos_t, sin_t;
+    sincos_cr(ang, &sin_t, &cos_t);
 
     float desc_tile[16];
     for (int i = 0; i < 16; i++) desc_tile[i] = 1.0f - fabsf(-1.0f + 1.0f / 16.0f + i * 1.0f / 8.0f);
@@ -1205,7 +1219,8 @@ static void descriptor_iloop_one(const oracle_ctx* c, const ext_t* e, float ang,
 
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (SBP == 0) return;
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    float cos_t, sin_t;
+    sincos_cr(ang, &sin_t, &cos_t);
     const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
     const float bsz = fabsf(cos_t) + fabsf(sin_t);
 

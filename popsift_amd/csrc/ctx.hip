@@ -79,6 +79,7 @@ struct popsift_hip_ctx {
     popsift_hip_feature* d_feats = nullptr;
     size_t   ext_cap = 0; /* entries in d_iext/d_ext/d_feats */
     int*     d_map = nullptr;
+    float2*  d_rot = nullptr; /* (cos, sin) of every descriptor's orientation, correctly rounded (k_scan_apply) */
     float*   d_desc = nullptr;
     int      desc_cap = 0;
     Counters* d_ct = nullptr;
@@ -214,11 +215,14 @@ int ensure_desc_cap(popsift_hip_ctx* c, int need)
     if (need <= c->desc_cap) return 0;
     if (c->d_desc) HIP_TRY(c, hipFree(c->d_desc));
     if (c->d_map) HIP_TRY(c, hipFree(c->d_map));
+    if (c->d_rot) HIP_TRY(c, hipFree(c->d_rot));
     c->d_desc = nullptr;
     c->d_map = nullptr;
+    c->d_rot = nullptr;
     c->desc_cap = 0;
     HIP_TRY(c, hipMalloc((void**)&c->d_desc, (size_t)need * 128 * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->d_map, (size_t)need * sizeof(int)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_rot, (size_t)need * sizeof(float2)));
     c->desc_cap = need;
     return 0;
 }
@@ -400,9 +404,9 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
     }
     HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ext, c->ori_blocks, c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
-    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->desc_cap,
+    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->d_rot, c->desc_cap,
                            c->stream));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_desc, c->desc_cap, c->desc_blocks,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->desc_blocks,
                                   c->stream));
     HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
@@ -699,6 +703,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_ext) (void)hipFree(c->d_ext);
     if (c->d_feats) (void)hipFree(c->d_feats);
     if (c->d_map) (void)hipFree(c->d_map);
+    if (c->d_rot) (void)hipFree(c->d_rot);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->d_ct) (void)hipFree(c->d_ct);
     if (c->d_pd) (void)hipFree(c->d_pd);

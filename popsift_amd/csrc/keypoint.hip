@@ -121,6 +121,47 @@ __device__ __forceinline__ float atan2_acc(float y, float x)
     return (y < 0.0f) ? -r : r;
 }
 
+/*
+ * cos / sin of the keypoint orientation, evaluated in double and rounded once: the same two floats as the oracle's
+ * sincos_cr (correctly rounded up to a ~1e-8 chance of double rounding).  |ang| <= pi (s_orientation.cu:222), so a
+ * quadrant reduction with pi/2 split in two doubles and Taylor polynomials on [-pi/4, pi/4] (truncation < 1e-19,
+ * rounding ~3e-16 relative) do it in ~35 double operations -- the library's double sincos with its large-argument
+ * path is far bigger.  Done once per descriptor in k_scan_apply and stored next to the descriptor -> extremum map: inside the descriptor kernels
+ * (64-register budget) any double arithmetic spilled and cost 5-9 %, inside k_orientation it raised the register
+ * count from 62 to 86.
+ */
+__device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
+{
+    const double x = (double)ang;
+    const double q = rint(x * 0.63661977236758134308);             /* 2/pi */
+    double       r = fma(-q, 1.57079632679489655800e+00, x);       /* pi/2, high part */
+    r = fma(-q, 6.12323399573676603587e-17, r);                     /* pi/2, low part  */
+    const double z = r * r;
+    double       ps = 2.81145725434552075980e-15;                    /* 1/17! */
+    ps = fma(ps, z, -7.64716373181981647590e-13);                    /* 1/15! */
+    ps = fma(ps, z, 1.60590438368216145994e-10);                     /* 1/13! */
+    ps = fma(ps, z, -2.50521083854417187751e-08);                    /* 1/11! */
+    ps = fma(ps, z, 2.75573192239858906526e-06);                     /* 1/9!  */
+    ps = fma(ps, z, -1.98412698412698412698e-04);                    /* 1/7!  */
+    ps = fma(ps, z, 8.33333333333333333333e-03);                     /* 1/5!  */
+    ps = fma(ps, z, -1.66666666666666666667e-01);                    /* 1/3!  */
+    const double sr = fma(ps * z, r, r);
+    double       pc = -1.56192069685862264622e-16;                   /* 1/18! */
+    pc = fma(pc, z, 4.77947733238738529744e-14);                     /* 1/16! */
+    pc = fma(pc, z, -1.14707455977297247139e-11);                    /* 1/14! */
+    pc = fma(pc, z, 2.08767569878680989792e-09);                     /* 1/12! */
+    pc = fma(pc, z, -2.75573192239858906526e-07);                    /* 1/10! */
+    pc = fma(pc, z, 2.48015873015873015873e-05);                     /* 1/8!  */
+    pc = fma(pc, z, -1.38888888888888888889e-03);                    /* 1/6!  */
+    pc = fma(pc, z, 4.16666666666666666667e-02);                     /* 1/4!  */
+    pc = fma(pc, z, -0.5);
+    const double cr = fma(pc, z, 1.0);
+    const int    n = (int)q & 3; /* quadrant: sin/cos of r + n pi/2 */
+    const double sd = (n & 1) ? cr : sr, cd = (n & 1) ? sr : cr;
+    s = (float)((n & 2) ? -sd : sd);
+    c = (float)(((n + 1) & 2) ? -cd : cd);
+}
+
 #ifndef KP_NW
 #define KP_NW 1 /* waves per workgroup of k_orientation / k_descriptor: the waves are independent (one keypoint each) */
 #endif
@@ -337,7 +378,7 @@ __global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ 
 __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc,
                                                     Counters* __restrict__ ct, Ext* __restrict__ ext,
                                                     const int* __restrict__ partial, int* __restrict__ map,
-                                                    int desc_cap)
+                                                    float2* __restrict__ rot, int desc_cap)
 {
     __shared__ int s_red[4];
     __shared__ int s_ps[PS_MAX_OCT + 1];
@@ -373,8 +414,15 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
             const int idx = ext[g].idx_ori + offset;
             const int n = ext[g].num_ori;
             ext[g].idx_ori = idx;
-            for (int q = 0; q < n; q++)
-                if (idx + q < desc_cap) map[idx + q] = g;
+            for (int q = 0; q < n; q++) {
+                if (idx + q < desc_cap) {
+                    map[idx + q] = g;
+                    /* the rotation of the descriptor frame, in double, here where registers are plentiful */
+                    float sn, cs;
+                    sincos_cr(ext[g].orientation[q], sn, cs);
+                    rot[idx + q] = make_float2(cs, sn);
+                }
+            }
             /* first extremum of an octave: start of that octave's descriptors (dct.ori_ps) */
             for (int o = 0; o < n_oct; o++)
                 if (g == s_ps[o] && s_ps[o + 1] > s_ps[o]) ct->ori_ps[o] = idx;
@@ -429,8 +477,8 @@ __device__ __forceinline__ float atan2_bins(float y, float x)
 __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
                                                        const float* __restrict__ arena, SiftConsts sc,
                                                        const Counters* __restrict__ ct, const Ext* __restrict__ ext,
-                                                       const int* __restrict__ map, float* __restrict__ desc,
-                                                       int desc_cap)
+                                                       const int* __restrict__ map, const float2* __restrict__ rot,
+                                                       float* __restrict__ desc, int desc_cap)
 {
     /* DCOPY private copies of the histogram per wave: neighbouring lanes sample neighbouring
      * pixels, which mostly fall into the same cell and orientation bin; spreading them over
@@ -451,8 +499,6 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
     for (int d = blockIdx.x * KP_NW + wave; d < total; d += gridDim.x * KP_NW) {
         const Ext*     e = ext + map[d];
         const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
-        const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
-        const float    ang = e->orientation[ko];
         const OctDesc* od = &pdp->o[e->octave];
         const int      width = od->w, height = od->h, pitch = od->pitch;
         const int      lvl = min(max(e->lpos, 0), L - 1);
@@ -472,7 +518,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
         const float fscale = scalbnf(1.0f, fbits);
         if (SBP != 0.0f) {
             float sin_t, cos_t;
-            sincosf(ang, &sin_t, &cos_t);
+            cos_t = rot[d].x;
+            sin_t = rot[d].y;
             const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
             const float crsbp = cos_t / SBP, srsbp = sin_t / SBP;
             const float bsz = fabsf(csbp) + fabsf(ssbp);
@@ -688,7 +735,8 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
                                                          const float* __restrict__ arena, SiftConsts sc,
                                                          const Counters* __restrict__ ct,
                                                          const Ext* __restrict__ ext, const int* __restrict__ map,
-                                                         float* __restrict__ desc, int desc_cap)
+                                                         const float2* __restrict__ rot, float* __restrict__ desc,
+                                                         int desc_cap)
 {
     __shared__ float s_feat[4][128];
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -713,7 +761,8 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
         feat[lane + 64] = 0.0f;
         if (SBP != 0.0f) {
             float sin_t, cos_t;
-            sincosf(ang, &sin_t, &cos_t);
+            cos_t = rot[d].x;
+            sin_t = rot[d].y;
             const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
             const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t; /* lft_dn  */
             const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;     /* rgt_stp */
@@ -835,7 +884,8 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
                                                            const float* __restrict__ arena, SiftConsts sc,
                                                            const Counters* __restrict__ ct,
                                                            const Ext* __restrict__ ext, const int* __restrict__ map,
-                                                           float* __restrict__ desc, int desc_cap)
+                                                           const float2* __restrict__ rot, float* __restrict__ desc,
+                                                           int desc_cap)
 {
     constexpr int    DCOPY = 2;
     /* notile: 256 points per cell, iloop: up to 1024, each <= 361 * 1: low halves stay below 2^32 */
@@ -853,8 +903,6 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
     for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
         const Ext*     e = ext + map[d];
         const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
-        const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
-        const float    ang = e->orientation[ko];
         const OctDesc* od = &pdp->o[e->octave];
         const int      width = od->w, height = od->h, pitch = od->pitch;
         const int      lvl = min(max(e->lpos, 0), L - 1);
@@ -867,7 +915,8 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
 
         if (sigma != 0.0f) {
             float sin_t, cos_t;
-            sincosf(ang, &sin_t, &cos_t);
+            cos_t = rot[d].x;
+            sin_t = rot[d].y;
             if (ILOOP) {
                 /* DescMode ILoop (s_desc_iloop.cu:18-133): every cell samples a FIXED 32 x 32 lattice over the
                  * bounding box of its rotated two-cell square and keeps the points inside the square; the
@@ -1027,29 +1076,30 @@ hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftC
 }
 
 hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
-                       int* map, int desc_cap, hipStream_t s)
+                       int* map, float2* rot, int desc_cap, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, desc_cap);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, desc_cap);
     return hipGetLastError();
 }
 
 int scan_chunk() { return SCAN_CHUNK; }
 
 hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
-                              const Ext* ext, const int* map, float* desc, int desc_cap, int blocks, hipStream_t s)
+                              const Ext* ext, const int* map, const float2* rot, float* desc, int desc_cap, int blocks,
+                              hipStream_t s)
 {
     /* IGrid (s_desc_igrid.cu:20-83) evaluates the same 40 x 40 point lattice with the same weights as NoTile,
      * cell by cell (each point up to four times); the two differ only in summation order (6e-7 relative in the
      * oracle), so both run the one-evaluation-per-point kernel */
     if (sc.desc_mode == POPSIFT_HIP_DESC_NOTILE || sc.desc_mode == POPSIFT_HIP_DESC_IGRID)
-        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_ILOOP)
-        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
-        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else
-        hipLaunchKernelGGL(k_descriptor, dim3(blocks * 4 / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, ext, map, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor, dim3(blocks * 4 / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     return hipGetLastError();
 }
 

@@ -445,13 +445,8 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
         }
         for (int y = 0; y < h; y++)
             memcpy((char*)c->h_input + (size_t)y * w * esz, (const char*)img + (size_t)y * pitch * esz, (size_t)w * esz);
-        static const bool zero_copy = getenv("POPSIFT_HIP_ZERO_COPY_INPUT") != nullptr;
-        if (zero_copy) {
-            d_img = c->h_input; /* pinned host memory is mapped into the device's address space */
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_input, bytes, hipMemcpyHostToDevice, c->stream));
-            d_img = c->d_input;
-        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_input, bytes, hipMemcpyHostToDevice, c->stream));
+        d_img = c->d_input;
         dpitch = w;
     }
     c->blur_events_used = 0;

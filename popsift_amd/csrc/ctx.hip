@@ -404,11 +404,10 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
     }
     HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ext, c->ori_blocks, c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
-    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->d_rot, c->desc_cap,
+    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_feats, c->desc_cap,
                            c->stream));
     HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->desc_blocks,
                                   c->stream));
-    HIP_TRY(c, launch_prep(c->sc, c->d_ct, c->d_ext, c->d_feats, c->desc_cap, 512, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     return 0;
 }

@@ -40,11 +40,9 @@ hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const Sif
                               Ext* ext, int blocks, hipStream_t s);
 int        scan_chunk(); /* extrema per scan workgroup */
 hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
-                       int* map, float2* rot, int desc_cap, hipStream_t s);
+                       int* map, float2* rot, popsift_hip_feature* feats, int desc_cap, hipStream_t s);
 hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, const Counters* ct, const Ext* ext,
                               const int* map, const float2* rot, float* desc, int desc_cap, int blocks, hipStream_t s);
-hipError_t launch_prep(const SiftConsts& sc, const Counters* ct, const Ext* ext, popsift_hip_feature* feats,
-                       int desc_cap, int blocks, hipStream_t s);
 
 /* filter.hip: grid filter between refinement and orientation (s_filtergrid.cu:109-322) */
 bool       filter_supported(int n_oct, int max_extrema, int grid_size);

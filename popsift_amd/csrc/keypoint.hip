@@ -14,7 +14,7 @@
  *   ext_desc_iloop        s_desc_iloop.cu:18-154    -> k_descriptor_notile<true>
  *   normalize_histogram   s_desc_normalize.h:14-33, s_desc_norm_rs.h, s_desc_norm_l2.h
  *                                                   -> fused into the descriptor kernels
- *   prep_features         sift_pyramid.cu:249-279   -> k_prep
+ *   prep_features         sift_pyramid.cu:249-279   -> fused into k_scan_apply
  */
 #include <hip/hip_runtime.h>
 
@@ -378,7 +378,8 @@ __global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ 
 __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc,
                                                     Counters* __restrict__ ct, Ext* __restrict__ ext,
                                                     const int* __restrict__ partial, int* __restrict__ map,
-                                                    float2* __restrict__ rot, int desc_cap)
+                                                    float2* __restrict__ rot, popsift_hip_feature* __restrict__ feats,
+                                                    int desc_cap)
 {
     __shared__ int s_red[4];
     __shared__ int s_ps[PS_MAX_OCT + 1];
@@ -411,18 +412,33 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int g = g0 + k;
         if (g < total) {
-            const int idx = ext[g].idx_ori + offset;
-            const int n = ext[g].num_ori;
+            Ext       e = ext[g];
+            const int idx = e.idx_ori + offset;
+            const int n = e.num_ori;
             ext[g].idx_ori = idx;
-            for (int q = 0; q < n; q++) {
-                if (idx + q < desc_cap) {
+            /* prep_features (sift_pyramid.cu:249-279): positions and scale in input-image coordinates,
+             * descriptor indices instead of pointers */
+            popsift_hip_feature f;
+            const float         scl = powf(2.0f, (float)(e.octave - sc.up_fac_int));
+            f.debug_octave = e.octave;
+            f.xpos = e.xpos * scl;
+            f.ypos = e.ypos * scl;
+            f.sigma = e.sigma * scl;
+            f.num_ori = n;
+#pragma unroll
+            for (int q = 0; q < POPSIFT_HIP_ORI_MAX; q++) {
+                const bool on = q < n && idx + q < desc_cap;
+                f.desc_idx[q] = on ? idx + q : -1;
+                f.orientation[q] = (q < n) ? e.orientation[q] : 0.0f;
+                if (on) {
                     map[idx + q] = g;
                     /* the rotation of the descriptor frame, in double, here where registers are plentiful */
                     float sn, cs;
-                    sincos_cr(ext[g].orientation[q], sn, cs);
+                    sincos_cr(e.orientation[q], sn, cs);
                     rot[idx + q] = make_float2(cs, sn);
                 }
             }
+            feats[g] = f;
             /* first extremum of an octave: start of that octave's descriptors (dct.ori_ps) */
             for (int o = 0; o < n_oct; o++)
                 if (g == s_ps[o] && s_ps[o + 1] > s_ps[o]) ct->ori_ps[o] = idx;
@@ -1042,29 +1058,6 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
 
 /* --------------------------------------------------------------- features */
 
-__global__ __launch_bounds__(256) void k_prep(SiftConsts sc, const Counters* __restrict__ ct,
-                                              const Ext* __restrict__ ext, popsift_hip_feature* __restrict__ feats,
-                                              int desc_cap)
-{
-    const int total = ct->ext_total;
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
-        const Ext           e = ext[g];
-        popsift_hip_feature f;
-        const float         scl = powf(2.0f, (float)(e.octave - sc.up_fac_int));
-        f.debug_octave = e.octave;
-        f.xpos = e.xpos * scl;
-        f.ypos = e.ypos * scl;
-        f.sigma = e.sigma * scl;
-        f.num_ori = e.num_ori;
-#pragma unroll
-        for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) {
-            const bool on = k < e.num_ori && e.idx_ori + k < desc_cap;
-            f.desc_idx[k] = on ? e.idx_ori + k : -1;
-            f.orientation[k] = (k < e.num_ori) ? e.orientation[k] : 0.0f;
-        }
-        feats[g] = f;
-    }
-}
 
 }  // namespace
 
@@ -1076,10 +1069,10 @@ hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftC
 }
 
 hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
-                       int* map, float2* rot, int desc_cap, hipStream_t s)
+                       int* map, float2* rot, popsift_hip_feature* feats, int desc_cap, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, desc_cap);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, feats, desc_cap);
     return hipGetLastError();
 }
 
@@ -1103,11 +1096,5 @@ hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftC
     return hipGetLastError();
 }
 
-hipError_t launch_prep(const SiftConsts& sc, const Counters* ct, const Ext* ext, popsift_hip_feature* feats,
-                       int desc_cap, int blocks, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_prep, dim3(blocks), dim3(256), 0, s, sc, ct, ext, feats, desc_cap);
-    return hipGetLastError();
-}
 
 }  // namespace popsift_hip

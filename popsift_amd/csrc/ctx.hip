@@ -373,15 +373,14 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
                     a.shift = shift;
                     const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * px;
                     if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
-                } else {
-                    const OctDesc& pv = pd.o[o - 1];
-                    HIP_TRY(c, launch_decimate(pv.data + (pd.L - 3) * pv.plane_stride, pv.w, pv.h, pv.pitch, a.dst,
-                                               od.w, od.h, od.pitch, c->stream));
                 }
+                /* o > 0: level 0 was written by the previous octave's level L-3 launch (BlurArgs::next0) */
             } else {
                 a.src = od.data + (level - 1) * od.plane_stride;
                 a.dog = od.dog + (level - 1) * od.plane_stride;
                 a.in = nullptr;
+                a.next0 = (level == pd.L - 3 && o + 1 < pd.n_oct) ? pd.o[o + 1].data : nullptr;
+                a.next_pitch = (o + 1 < pd.n_oct) ? pd.o[o + 1].pitch : 0;
                 /* read plane l-1 once, write plane l and DoG l-1 once: 12 B / pixel */
                 if (int rc = blur_launch(c, a, 0, c->tab.span[level], thd, 12.0 * px)) return rc;
             }

@@ -22,13 +22,15 @@ struct BlurArgs {
     int          in_w, in_h, in_pitch;
     float        shift;
     Taps         taps;
+    /* level L-3 only: level 0 of the next octave = every second pixel of this plane (get_by_2_pick_every_second,
+     * s_pyramid_build.cu:50-71), written by the same launch; null otherwise */
+    float*       next0;
+    int          next_pitch;
 };
 
 int        blur_tile_w();
 int        blur_tile_h(int w, int h); /* 32 or 64 rows, by plane size */
 hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s);
-hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* dst, int dw, int dh,
-                           int dpitch, hipStream_t s);
 
 /* extrema.hip */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */

@@ -328,6 +328,13 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
                     if (MODE == 0)
                         __builtin_nontemporal_store(acc - old[g][o], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
+                    /* the next octave's level 0 takes pixel (2x, 2y): its width is ceil(w / 2), so 2x <= w - 1 always
+                     * and the reference's min(2x, w - 1) never clamps.  gx is a multiple of 4. */
+                    if (MODE == 0 && a.next0 && (gy & 1) == 0) {
+                        float* q = a.next0 + (size_t)(gy >> 1) * a.next_pitch + (gx >> 1);
+                        q[0] = acc.x;
+                        if (gx + 2 < w) q[1] = acc.z;
+                    }
                 }
             }
         }
@@ -335,17 +342,6 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 }
 
 /* get_by_2_pick_every_second (s_pyramid_build.cu:50-71) */
-__global__ __launch_bounds__(256) void k_decimate(const float* __restrict__ src, int sw, int sh, int spitch,
-                                                  float* __restrict__ dst, int dw, int dh, int dpitch)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
-    const int rx = min(x << 1, sw - 1);
-    const int ry = min(y << 1, sh - 1);
-    dst[(size_t)y * dpitch + x] = src[(size_t)ry * spitch + rx];
-}
-
 template <int MODE, int TH, int NT>
 hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
 {
@@ -419,12 +415,5 @@ hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStr
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_decimate(const float* src, int sw, int sh, int spitch, float* dst, int dw, int dh,
-                           int dpitch, hipStream_t s)
-{
-    const dim3 grid((dw + 63) / 64, (dh + 3) / 4), block(256);
-    hipLaunchKernelGGL(k_decimate, grid, block, 0, s, src, sw, sh, spitch, dst, dw, dh, dpitch);
-    return hipGetLastError();
-}
 
 }  // namespace popsift_hip

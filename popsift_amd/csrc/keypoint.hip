@@ -7,7 +7,7 @@
  *
  * Replaces:
  *   ori_par               s_orientation.cu:60-242   -> k_orientation (1 wave / extremum)
- *   ori_prefix_sum        s_orientation.cu:303-345  -> k_scan_local + k_scan_apply (2048 extrema / workgroup)
+ *   ori_prefix_sum        s_orientation.cu:303-345  -> k_scan_local + k_scan_apply (256 extrema / workgroup)
  *   ext_desc_loop(+_sub)  s_desc_loop.cu:19-161     -> k_descriptor (1 wave / descriptor)
  *   ext_desc_grid         s_desc_grid.cu:19-147     -> k_descriptor_grid
  *   ext_desc_notile/igrid s_desc_notile.cu:28-166, s_desc_igrid.cu:20-109 -> k_descriptor_notile<false>
@@ -329,7 +329,9 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
  * default 9 x 100000 capacity, summed redundantly per workgroup) and writes the
  * map and the counters.
  */
-constexpr int SCAN_ITEMS = 8;
+/* extrema per lane: 1 -- the per-extremum work of k_scan_apply (feature record, double-precision cos / sin)
+ * is serial per lane, so wide beats deep (8 per lane: 22.8 us, 2: 10.2 us, 1: 7.5 us) */
+constexpr int SCAN_ITEMS = 1;
 constexpr int SCAN_CHUNK = 256 * SCAN_ITEMS;
 
 __device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConsts& sc, int n_oct)

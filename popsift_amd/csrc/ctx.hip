@@ -241,6 +241,8 @@ int ensure_cand_cap(popsift_hip_ctx* c, int need)
 /* Pyramid::Pyramid / resetDimensions: sizes for this image, grow-only arena */
 int prepare_geometry(popsift_hip_ctx* c, int w, int h)
 {
+    /* same size as the previous image of this context: planes, descriptors and the device copy of the geometry stand */
+    if (c->have_image && w == c->in_w && h == c->in_h && c->pd.n_oct > 0) return 0;
     int n_oct, bw, bh;
     plan_dims(c, w, h, c->frozen_octaves, &n_oct, &bw, &bh);
     c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */

@@ -14,10 +14,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <sstream>
+#include <vector>
 
 #include "debug_dump.h"
 #include "popsift/common/device_prop.h"
@@ -86,6 +88,40 @@ std::vector<int> device_list()
     }
     if (devs.empty()) DIE("POPSIFT_DEVICES is empty");
     return devs;
+}
+
+/* Config::setPrintGaussTables (--print-gauss-tables): the preamble of init_filter (gauss_filter.cu:147-163) and the
+ * "relative sigma" block of print_gauss_filter_symbol (gauss_filter.cu:24-47), the one table this build applies
+ * (the reference also prints its hardware-interpolation and absolute-filter tables, which do not exist here) */
+void print_gauss_tables(const popsift::Config& conf, popsift_hip_ctx* ctx)
+{
+    int n = 0;
+    if (popsift_hip_get_gauss_table(ctx, 0, 0, 0, &n) != POPSIFT_HIP_OK || n <= 0) return;
+    std::vector<float> filter((size_t)n * POPSIFT_HIP_GAUSS_ALIGN), sigma((size_t)n);
+    std::vector<int>   span((size_t)n);
+    if (popsift_hip_get_gauss_table(ctx, filter.data(), span.data(), sigma.data(), &n) != POPSIFT_HIP_OK) return;
+    printf("\n"
+           "Upscaling factor: %f (i.e. original image is scaled by a factor of %f)\n"
+           "\n"
+           "Sigma computations\n"
+           "    Initial sigma is %f\n"
+           "    Input blurriness is assumed to be %f (scaled to %f)\n",
+           conf.getUpscaleFactor(), pow(2.0f, conf.getUpscaleFactor()), conf.sigma, conf.getInitialBlur(),
+           conf.getInitialBlur() * pow(2.0f, conf.getUpscaleFactor()));
+    printf("\n"
+           "Gauss tables\n"
+           "      level span sigma : center value -> edge value\n"
+           "    relative sigma\n");
+    const int columns = 10;
+    for (int lvl = 0; lvl < n; lvl++) {
+        printf("      %d %d ", lvl, span[(size_t)lvl] + span[(size_t)lvl] - 1);
+        printf("%2.6f: ", sigma[(size_t)lvl]);
+        const int m = std::min(span[(size_t)lvl], columns);
+        for (int x = 0; x < m; x++) printf("%0.8f ", filter[(size_t)lvl * POPSIFT_HIP_GAUSS_ALIGN + x]);
+        printf(m < span[(size_t)lvl] ? "...\n" : "\n");
+    }
+    printf("\n");
+    fflush(stdout);
 }
 
 int contexts_per_device()
@@ -179,6 +215,7 @@ void PopSift::start_workers(int w, int h)
             _workers.push_back(wk);
         }
     }
+    if (_config.ifPrintGaussTables() && !_workers.empty()) print_gauss_tables(_config, _workers[0]->ctx);
     for (Worker* wk : _workers) wk->thread = std::thread(&PopSift::worker_loop, this, wk);
     _started = true;
 }

@@ -97,12 +97,14 @@ def test_demo_program_matches_c_abi(gpu_hip, tmp_path):
         assert r.stdout.splitlines()[0] == p                      # main.cpp:278
         assert _counts(r.stderr) == [(len(feats), len(desc))]
         _check_rows(np.loadtxt(str(tmp_path / "output-features.txt"), ndmin=2), feats, desc)
-    r = subprocess.run([DEMO, "--input-file=" + str(d), "--dont-write", "--print-dev-info", "--print-time-info"],
+    r = subprocess.run([DEMO, "--input-file=" + str(d), "--dont-write", "--print-dev-info", "--print-time-info",
+                        "--print-gauss-tables"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     assert sorted(_counts(r.stderr)) == sorted((len(f), len(x)) for f, x in want)
     assert "is directory" in r.stdout and "Choosing device 0" in r.stdout and "Device information:" in r.stdout
     assert "Warp size:             64" in r.stdout
+    assert "    relative sigma" in r.stdout and "      5 27 3.09" in r.stdout      # level 5: 27 taps, sigma 3.090
 
 
 @pytest.mark.gpu

@@ -69,6 +69,16 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+/* a value every lane of the wave holds identically, moved to scalar registers */
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ long long uniform64(long long v)
+{
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)(v & 0xffffffffll));
+    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 /* clamped extrema counts -> exclusive prefix (uniform, <= 20 entries) */
 __device__ __forceinline__ int ext_prefix(const Counters* ct, const SiftConsts& sc, int n_oct, int* ps)
 {
@@ -185,9 +195,9 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         while (o + 1 < n_oct && g >= ps[o + 1]) o++;
         const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - ps[o])];
         const OctDesc* od = &pdp->o[o];
-        const int      w = od->w, h = od->h, pitch = od->pitch;
+        const int      w = uniform(od->w), h = uniform(od->h), pitch = uniform(od->pitch);
         const int      lvl = min(max(ie.lpos, 0), L - 1);
-        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
+        const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
 
         if (lane < PS_ORI_NBINS) hist[lane] = 0ull;
         wave_lds_sync();
@@ -516,11 +526,13 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
 
     for (int d = blockIdx.x * KP_NW + wave; d < total; d += gridDim.x * KP_NW) {
         const Ext*     e = ext + map[d];
-        const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
+        const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
         const OctDesc* od = &pdp->o[e->octave];
-        const int      width = od->w, height = od->h, pitch = od->pitch;
+        /* everything about the descriptor is wave-uniform: say so, and the plane base, the pitch and the bounds live in
+         * scalar registers (the taps become scalar-base + 32-bit-offset loads): 574 -> 539 us */
+        const int      width = uniform(od->w), height = uniform(od->h), pitch = uniform(od->pitch);
         const int      lvl = min(max(e->lpos, 0), L - 1);
-        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
+        const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
 
 #pragma unroll
         for (int k = 0; k < 2 * DCOPY; k++) hall[lane + 64 * k] = 0ull;
@@ -536,8 +548,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
         const float fscale = scalbnf(1.0f, fbits);
         if (SBP != 0.0f) {
             float sin_t, cos_t;
-            cos_t = rot[d].x;
-            sin_t = rot[d].y;
+            cos_t = uniformf(rot[d].x);
+            sin_t = uniformf(rot[d].y);
             const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
             const float crsbp = cos_t / SBP, srsbp = sin_t / SBP;
             const float bsz = fabsf(csbp) + fabsf(ssbp);
@@ -770,9 +782,9 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
         const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
         const float    ang = e->orientation[ko];
         const OctDesc* od = &pdp->o[e->octave];
-        const int      width = od->w, height = od->h, pitch = od->pitch;
+        const int      width = uniform(od->w), height = uniform(od->h), pitch = uniform(od->pitch);
         const int      lvl = min(max(e->lpos, 0), L - 1);
-        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
+        const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
         const float    SBP = fabsf(DESC_MAGNIFY * sigma);
 
         feat[lane] = 0.0f;
@@ -922,9 +934,9 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
         const Ext*     e = ext + map[d];
         const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
         const OctDesc* od = &pdp->o[e->octave];
-        const int      width = od->w, height = od->h, pitch = od->pitch;
+        const int      width = uniform(od->w), height = uniform(od->h), pitch = uniform(od->pitch);
         const int      lvl = min(max(e->lpos, 0), L - 1);
-        const float*   layer = arena + od->data_off + lvl * od->plane_stride;
+        const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
         const float    SBP = fabsf(DESC_MAGNIFY * sigma);
 
 #pragma unroll

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
 
     for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
         const Ext*     e = ext + map[d];
-        const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
+        const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
         const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
         const float    ang = e->orientation[ko];
         const OctDesc* od = &pdp->o[e->octave];
@@ -791,8 +791,8 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
         feat[lane + 64] = 0.0f;
         if (SBP != 0.0f) {
             float sin_t, cos_t;
-            cos_t = rot[d].x;
-            sin_t = rot[d].y;
+            cos_t = uniformf(rot[d].x);
+            sin_t = uniformf(rot[d].y);
             const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
             const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t; /* lft_dn  */
             const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;     /* rgt_stp */
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
 
     for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
         const Ext*     e = ext + map[d];
-        const float    x = e->xpos, y = e->ypos, sigma = e->sigma;
+        const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
         const OctDesc* od = &pdp->o[e->octave];
         const int      width = uniform(od->w), height = uniform(od->h), pitch = uniform(od->pitch);
         const int      lvl = min(max(e->lpos, 0), L - 1);
@@ -945,8 +945,8 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
 
         if (sigma != 0.0f) {
             float sin_t, cos_t;
-            cos_t = rot[d].x;
-            sin_t = rot[d].y;
+            cos_t = uniformf(rot[d].x);
+            sin_t = uniformf(rot[d].y);
             if (ILOOP) {
                 /* DescMode ILoop (s_desc_iloop.cu:18-133): every cell samples a FIXED 32 x 32 lattice over the
                  * bounding box of its rotated two-cell square and keeps the points inside the square; the

@@ -71,6 +71,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 /*
  * MODE 0: level l >= 1 from plane l-1 (centre tap first in the H pass, DoG out)
@@ -309,16 +310,23 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int cpos = HALO + o;
-                v4f       acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                /* explicit 2-vectors: every FMA of the chain is a v_pk_fma_f32 (left to itself the compiler
+                 * goes scalar on the rows whose x / z lanes also feed the next octave: 68 instead of 34) */
+                v2f alo = {0.0f, 0.0f}, ahi = {0.0f, 0.0f};
 #pragma unroll
                 for (int k = HALO; k > 0; k--) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) acc[e] = fmaf(win[cpos - k][e], a.taps.g[k], acc[e]);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) acc[e] = fmaf(win[cpos + k][e], a.taps.g[k], acc[e]);
+                    const v2f gk = {a.taps.g[k], a.taps.g[k]};
+                    alo = __builtin_elementwise_fma(win[cpos - k].lo, gk, alo);
+                    ahi = __builtin_elementwise_fma(win[cpos - k].hi, gk, ahi);
+                    alo = __builtin_elementwise_fma(win[cpos + k].lo, gk, alo);
+                    ahi = __builtin_elementwise_fma(win[cpos + k].hi, gk, ahi);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc[e] = fmaf(win[cpos][e], a.taps.g[0], acc[e]);
+                {
+                    const v2f g0 = {a.taps.g[0], a.taps.g[0]};
+                    alo = __builtin_elementwise_fma(win[cpos].lo, g0, alo);
+                    ahi = __builtin_elementwise_fma(win[cpos].hi, g0, ahi);
+                }
+                const v4f acc = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3);
                 const int gy = ty0 + r0 + o;
                 if (gx < w && gy < h) {
                     /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */

@@ -119,6 +119,11 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                 const int    gy = clampi(ty0 + r - HALO, 0, h - 1);
                 const int    gx0 = tx0 + 4 * c4 - HP;
                 const float* row = src + (size_t)gy * pitch;
+#ifdef BLUR_NO_LOAD /* tools/blur_phase_probe.sh: timing probe, results are wrong */
+                if (true) {
+                    v[k] = v4f{(float)gx0, (float)gy, 1.0f, 2.0f};
+                } else
+#endif
                 if (gx0 >= 0 && gx0 + 3 < w) {
                     v[k] = *reinterpret_cast<const v4f*>(row + gx0);
                 } else {
@@ -333,9 +338,13 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                     /* the Gaussian plane is the next level's input (keep it cached); the DoG plane is not touched again
                      * before the detection kernel: a non-temporal store keeps it from evicting the plane
                      * (measured: level launches -4 %, detection -7 %; non-temporal for both: levels +20 %) */
+#ifdef BLUR_NO_STORE /* tools/blur_phase_probe.sh: timing probe, results are wrong */
+                    if (acc.x == 1.2345e30f) a.dst[0] = acc.y + old[g][o].x;
+#else
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
                     if (MODE == 0)
                         __builtin_nontemporal_store(acc - old[g][o], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
+#endif
                     /* the next octave's level 0 takes pixel (2x, 2y): its width is ceil(w / 2), so 2x <= w - 1 always
                      * and the reference's min(2x, w - 1) never clamps.  gx is a multiple of 4. */
                     if (MODE == 0 && a.next0 && (gy & 1) == 0) {

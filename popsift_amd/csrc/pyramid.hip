@@ -297,9 +297,14 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
     for (int g = 0; g < GROUPS; g++) {
         const int rg = (tid >> 5) + g * (NT / 32);
 #pragma unroll
+#ifdef BLUR_NO_H /* tools/blur_phase_probe.sh: timing probe, results are wrong */
+        for (int j = 0; j < 4; j++) old[g][j] = *reinterpret_cast<const v4f*>(&s_t[(HALO + 4 * rg + j) * SW + HP + lx]);
+    }
+#else
         for (int j = 0; j < 4; j++) old[g][j] = hrow(HALO + 4 * rg + j);
     }
     for (int hh = tid >> 5; hh < 2 * HALO; hh += NT / 32) (void)hrow(hh < HALO ? hh : TH + hh);
+#endif
     __syncthreads();
 
     /* ---- phase 3: vertical pass, 4 columns x 4 rows per lane, + DoG ------ */
@@ -331,7 +336,11 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                     alo = __builtin_elementwise_fma(win[cpos].lo, g0, alo);
                     ahi = __builtin_elementwise_fma(win[cpos].hi, g0, ahi);
                 }
+#ifdef BLUR_NO_V /* tools/blur_phase_probe.sh: timing probe, results are wrong */
+                const v4f acc = win[cpos] + win[cpos + HALO] + win[cpos - HALO];
+#else
                 const v4f acc = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3);
+#endif
                 const int gy = ty0 + r0 + o;
                 if (gx < w && gy < h) {
                     /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: kernel times of the octave-0 blur launches for the build_variants/ libraries; build them first with
-#   bash tools/build_variants.sh "-DV0" "-DBLUR_NO_STORE" "-DBLUR_NO_LOAD" "-DBLUR_NO_STORE -DBLUR_NO_LOAD"
+#   bash tools/build_variants.sh "-DV0" "-DBLUR_NO_STORE" "-DBLUR_NO_LOAD" "-DBLUR_NO_STORE -DBLUR_NO_LOAD" "-DBLUR_NO_H -DBLUR_NO_V"
+# (also -DBLUR_NO_H / -DBLUR_NO_V alone or combined with the two above)
 # variants are wrong by construction: only the times matter)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/blurprobe; rm -rf $OUT; mkdir -p $OUT

@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context roofline pass (the command profiles/ *_roofline_pass* was taken with)")
-    ap.add_argument("--cpu-images", type=int, default=2, help="images timed for the CPU baseline")
+    ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
     return ap.parse_args()
 
 

@@ -79,6 +79,32 @@ __device__ __forceinline__ long long uniform64(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+/* The four gradient taps around plane element `off` (>= pitch + 1, so every tap is in the plane).  `layer` and
+ * `pitch` are wave-uniform: with an UNSIGNED 32-bit byte offset the loads take the scalar-base + vector-offset
+ * form (three scalar bases: the row, the row below, the row above) instead of 64-bit vector address arithmetic
+ * per tap.  A plane is far below 4 GiB (the arena's largest is 7680 x 4320 floats). */
+struct Taps {
+    const char* row;
+    const char* dn;
+    const char* up;
+    __device__ __forceinline__ Taps(const float* layer, int pitch)
+        : row((const char*)layer), dn((const char*)(layer + pitch)), up((const char*)(layer - pitch)) {}
+    __device__ __forceinline__ void load(int off, float& xp, float& xm, float& yp, float& ym) const
+    {
+        const size_t b = (unsigned int)off * 4u;
+        xp = *(const float*)(row + b + 4);
+        xm = *(const float*)(row + b - 4);
+        yp = *(const float*)(dn + b);
+        ym = *(const float*)(up + b);
+    }
+};
+
+/* element `idx` >= 0 of a wave-uniform plane through an unsigned 32-bit byte offset (scalar base + vector offset) */
+__device__ __forceinline__ float plane_at(const float* pl, int idx)
+{
+    return *(const float*)((const char*)pl + (size_t)((unsigned int)idx * 4u));
+}
+
 /* clamped extrema counts -> exclusive prefix (uniform, <= 20 entries) */
 __device__ __forceinline__ int ext_prefix(const Counters* ct, const SiftConsts& sc, int n_oct, int* ps)
 {
@@ -224,24 +250,17 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         };
         int   xn = xmin, yn = ymin;
         float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+        const Taps taps(layer, pitch);
         if (loops > 0) {
             coord(min(lane, loops - 1), xn, yn);
-            const float* c = layer + (__mul24(yn, pitch) + xn);
-            g0 = c[1];
-            g1 = c[-1];
-            g2 = c[pitch];
-            g3 = c[-pitch];
+            taps.load(__mul24(yn, pitch) + xn, g0, g1, g2, g3);
         }
         for (int i = lane; i < loops; i += 64) {
             const int   xx = xn, yy = yn;
             const float gdx = g0 - g1, gdy = g2 - g3;
             {
                 coord(min(i + 64, loops - 1), xn, yn);
-                const float* c = layer + (__mul24(yn, pitch) + xn);
-                g0 = c[1];
-                g1 = c[-1];
-                g2 = c[pitch];
-                g3 = c[-pitch];
+                taps.load(__mul24(yn, pitch) + xn, g0, g1, g2, g3);
             }
             const float dx = xx - x;
             const float dy = yy - y;
@@ -645,24 +664,17 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
             };
             int   off_n = 0;
             float u_n = 3.0f, v_n = 3.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+            const Taps taps(layer, pitch);
             if (loops > 0) {
                 coord(min(lane, loops - 1), off_n, u_n, v_n);
-                const float* c = layer + off_n;
-                g0 = c[1];
-                g1 = c[-1];
-                g2 = c[pitch];
-                g3 = c[-pitch];
+                taps.load(off_n, g0, g1, g2, g3);
             }
             for (int i = lane; i < loops; i += 64) {
                 const float u = u_n, v = v_n;
                 const float gx = g0 - g1, gy = g2 - g3;
                 {
                     coord(min(i + 64, loops - 1), off_n, u_n, v_n);
-                    const float* c = layer + off_n;
-                    g0 = c[1];
-                    g1 = c[-1];
-                    g2 = c[pitch];
-                    g3 = c[-pitch];
+                    taps.load(off_n, g0, g1, g2, g3);
                 }
                 if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
                     const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
@@ -818,9 +830,9 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
                     const int    xc = min(max(gx, 0), width - 1), yc = min(max(gy, 0), height - 1);
                     const int    xl = min(max(gx - 1, 0), width - 1), xr = min(max(gx + 1, 0), width - 1);
                     const int    yu = min(max(gy - 1, 0), height - 1), yl = min(max(gy + 1, 0), height - 1);
-                    const float* rowc = layer + __mul24(yc, pitch);
-                    const float  dxv = rowc[xr] - rowc[xl];
-                    const float  dyv = layer[__mul24(yl, pitch) + xc] - layer[__mul24(yu, pitch) + xc];
+                    const int    rowc = __mul24(yc, pitch);
+                    const float  dxv = plane_at(layer, rowc + xr) - plane_at(layer, rowc + xl);
+                    const float  dyv = plane_at(layer, __mul24(yl, pitch) + xc) - plane_at(layer, __mul24(yu, pitch) + xc);
                     const float  mod = __builtin_amdgcn_sqrtf(dxv * dxv + dyv * dyv);
                     float        th = atan2_acc(dyv, dxv);
                     const float  npx = fmaf(cos_t, pixox, sin_t * pixoy);
@@ -892,10 +904,10 @@ __device__ __forceinline__ float tex_linear(const float* pl, int w, int h, int p
     b = floorf(b * 256.0f + 0.5f) * (1.0f / 256.0f);
     const int    i = (int)fx, j = (int)fy;
     const int    x0 = min(max(i, 0), w - 1), x1 = min(max(i + 1, 0), w - 1);
-    const float* r0 = pl + __mul24(min(max(j, 0), h - 1), pitch);
-    const float* r1 = pl + __mul24(min(max(j + 1, 0), h - 1), pitch);
-    const float  top = (1.0f - a) * r0[x0] + a * r0[x1];
-    const float  bot = (1.0f - a) * r1[x0] + a * r1[x1];
+    const int    r0 = __mul24(min(max(j, 0), h - 1), pitch);
+    const int    r1 = __mul24(min(max(j + 1, 0), h - 1), pitch);
+    const float  top = (1.0f - a) * plane_at(pl, r0 + x0) + a * plane_at(pl, r0 + x1);
+    const float  bot = (1.0f - a) * plane_at(pl, r1 + x0) + a * plane_at(pl, r1 + x1);
     return (1.0f - b) * top + b * bot;
 }
 

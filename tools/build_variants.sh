@@ -10,7 +10,8 @@ for V in "$@"; do
   OBJS=""
   for f in $(sed -n 's/^SRCS *= *//p' Makefile); do
     b=${f%.hip}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $V -c $f -o /tmp/var_$b.o || exit 1
+    X=$(sed -n "s/^FLAGS_$b *= *//p" Makefile)   # the Makefile's per-file flags
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $X $V -c $f -o /tmp/var_$b.o || exit 1
     OBJS="$OBJS /tmp/var_$b.o"
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/v$i.so $OBJS || exit 1

@@ -258,6 +258,12 @@ __device__ bool refine(const DogView& dog, const SiftConsts& sc, int x, int y, i
  * s_extrema.cu:56-120 without any divergent load.  (A first version shifted lanes with wave-wide DPP
  * instead of loading the neighbours; those shifts stalled the wave for tens of cycles each on gfx950.)
  */
+__device__ __forceinline__ int xcd_run(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 constexpr int DET_W = 64;
 constexpr int DET_RH = 32;
 
@@ -298,7 +304,12 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
                                 : (MODE == POPSIFT_HIP_SIFT_VLFEAT) ? 0.8f * 2.0f * sc.threshold
                                                                     : 1.6f * sc.threshold;
 
-    for (int ui = blockIdx.x * 4 + (threadIdx.x >> 6); ui < n_units; ui += gridDim.x * 4) {
+    /* Workgroups b and b+8 share an XCD and its L2: hand each XCD a contiguous run of units (a horizontal band of
+     * the plane), so the cache lines that neighbouring strips share -- the column to the left and right of a
+     * workgroup's 256 columns, the row above and below its 32 rows -- are fetched from HBM once instead of
+     * once per XCD. */
+    const int wg = SLOW ? (int)blockIdx.x : xcd_run(blockIdx.x, gridDim.x);
+    for (int ui = wg * 4 + (threadIdx.x >> 6); ui < n_units; ui += gridDim.x * 4) {
         const int unit = SLOW ? ovf[ui] : ui;
         int       o = 0;
         while (o + 1 < n_oct && unit >= pdp->o[o + 1].tile_begin) o++;
@@ -346,6 +357,12 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
             for (int z = 0; z < NP; z++) {
+#ifdef DET_NO_LOAD /* timing probe (tools/desc_variants.sh): results are wrong */
+                raw[3 * z + 0] = (float)(y * 3 + z) * 1e-3f;
+                raw[3 * z + 1] = (float)(xl + z) * 1e-3f;
+                raw[3 * z + 2] = (float)(xr - y) * 1e-3f;
+                continue;
+#endif
                 raw[3 * z + 0] = p[z * od.plane_stride + xc];
                 raw[3 * z + 1] = p[z * od.plane_stride + xl];
                 raw[3 * z + 2] = p[z * od.plane_stride + xr];
@@ -428,8 +445,17 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
                 float q[DET_G][3 * NP];
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + k + 1, ye + 1), q[k]);
+#ifdef DET_NO_STEP /* timing probe: loads only */
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < DET_G; k++)
+#pragma unroll
+                    for (int j = 0; j < 3 * NP; j++) acc += q[k][j];
+                if (acc == 1.2345e30f) overflow = true;
+#else
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) step(y0 + k, q[k]);
+#endif
             }
             if (overflow) {
                 /* too many candidates for the queue: leave the whole strip to the SLOW pass */

@@ -364,6 +364,11 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
                 continue;
 #endif
                 raw[3 * z + 0] = p[z * od.plane_stride + xc];
+#ifdef DET_ONE_LOAD /* timing probe with DET_NO_STEP: one load per row and plane */
+                raw[3 * z + 1] = 0.0f;
+                raw[3 * z + 2] = 0.0f;
+                continue;
+#endif
                 raw[3 * z + 1] = p[z * od.plane_stride + xl];
                 raw[3 * z + 2] = p[z * od.plane_stride + xr];
             }

@@ -255,6 +255,11 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     pd.n_oct = n_oct;
     pd.levels = c->levels;
     pd.L = c->L;
+    /* POPSIFT_HIP_DOG_FLY=1: the blur kernel does not store DoG planes; detection and refinement subtract the Gaussian
+     * planes they load (bit-identical results, 33 % fewer bytes per level launch -- but refinement's scattered
+     * neighbourhood reads double, which for now eats the gain: off by default) */
+    static const int dog_fly = []() { const char* e = getenv("POPSIFT_HIP_DOG_FLY"); return e ? atoi(e) : 0; }();
+    pd.dog_fly = dog_fly ? 1 : 0;
     size_t total = 0;
     int    ow = bw, oh = bh, tiles = 0;
     for (int o = 0; o < n_oct; o++) {
@@ -379,12 +384,12 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
                 /* o > 0: level 0 was written by the previous octave's level L-3 launch (BlurArgs::next0) */
             } else {
                 a.src = od.data + (level - 1) * od.plane_stride;
-                a.dog = od.dog + (level - 1) * od.plane_stride;
+                a.dog = pd.dog_fly ? nullptr : od.dog + (level - 1) * od.plane_stride;
                 a.in = nullptr;
                 a.next0 = (level == pd.L - 3 && o + 1 < pd.n_oct) ? pd.o[o + 1].data : nullptr;
                 a.next_pitch = (o + 1 < pd.n_oct) ? pd.o[o + 1].pitch : 0;
-                /* read plane l-1 once, write plane l and DoG l-1 once: 12 B / pixel */
-                if (int rc = blur_launch(c, a, 0, c->tab.span[level], thd, 12.0 * px)) return rc;
+                /* read plane l-1 once, write plane l (and DoG l-1 when it is stored) once: 8 (12) B / pixel */
+                if (int rc = blur_launch(c, a, 0, c->tab.span[level], thd, (pd.dog_fly ? 8.0 : 12.0) * px)) return rc;
             }
         }
     }
@@ -1042,6 +1047,9 @@ int popsift_hip_download_plane(popsift_hip_ctx* c, int octave, int kind, int lev
     if (!out) return POPSIFT_HIP_ERR_INVALID;
     if (int rc = plane_ptr(c, octave, kind, level, &p, &od)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (kind == 1 && c->pd.dog_fly) /* not stored: DoG(l) = G(l+1) - G(l) into the (otherwise unused) DoG plane */
+        HIP_TRY(c, launch_dog_plane(p, od->data + (level + 1) * od->plane_stride, od->data + level * od->plane_stride,
+                                    (size_t)od->plane_stride, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy2D(out, (size_t)od->w * 4, p, (size_t)od->pitch * 4, (size_t)od->w * 4, od->h,
                            hipMemcpyDeviceToHost));

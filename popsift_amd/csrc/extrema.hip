@@ -27,21 +27,20 @@ namespace {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+template <bool FLY>
 struct DogView {
-    const float* base;
+    const float* base;  /* stored DoG planes, or (fly) the Gaussian planes: DoG(z) = G(z+1) - G(z), the subtraction
+                         * make_dog does (s_pyramid_build.cu:74-92) on the very same f32 values */
     int64_t      ps;
     int          w, h, pitch, nl; /* nl = number of DoG planes */
+    __device__ __forceinline__ float raw(int x, int y, int z) const /* caller guarantees 0<=x<w, 0<=y<h, 0<=z<nl */
+    {
+        const float* q = base + z * ps + (int64_t)y * pitch + x;
+        return FLY ? q[ps] - q[0] : q[0];
+    }
     __device__ __forceinline__ float at(int x, int y, int z) const
     {
-        x = clampi(x, 0, w - 1);
-        y = clampi(y, 0, h - 1);
-        z = clampi(z, 0, nl - 1);
-        return base[z * ps + (int64_t)y * pitch + x];
-    }
-    /* caller guarantees 0<=x<w, 0<=y<h, 0<=z<nl */
-    __device__ __forceinline__ float raw(int x, int y, int z) const
-    {
-        return base[z * ps + (int64_t)y * pitch + x];
+        return raw(clampi(x, 0, w - 1), clampi(y, 0, h - 1), clampi(z, 0, nl - 1));
     }
 };
 
@@ -109,8 +108,8 @@ __device__ __forceinline__ int f2i_sat(float f)
 }
 
 /* s_extrema.cu:300-504 (after the contrast + 26-neighbour tests) */
-template <int MODE>
-__device__ bool refine(const DogView& dog, const SiftConsts& sc, int x, int y, int level, float val,
+template <int MODE, bool FLY>
+__device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int y, int level, float val,
                        int maxlevel, InitExt& ec)
 {
     const int width = dog.w, height = dog.h;
@@ -288,7 +287,7 @@ struct RowRed {
 constexpr int DET_G = 4;   /* rows per load group (2 and 8, and a double-buffered variant, measured no better) */
 constexpr int DET_Q = 512; /* per-wave candidate queue (entries) */
 
-template <int MODE, int LEVELS, bool SLOW>
+template <int MODE, int LEVELS, bool SLOW, bool FLY>
 __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
                                                 SiftConsts sc, Counters* __restrict__ ct, int2* __restrict__ cand,
                                                 int cand_cap, int* __restrict__ ovf)
@@ -348,7 +347,8 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         /* left / centre / right neighbours are three overlapping row loads (same cache lines, the
          * texture path sorts it out) rather than lane shifts: wave-wide DPP shifts turned out to
          * stall the wave for tens of cycles each on gfx950 */
-        const float* base = arena + od.dog_off;
+        const float* base = arena + (FLY ? od.data_off : od.dog_off);
+        constexpr int NRAW = FLY ? 3 * (NP + 1) : 3 * NP; /* FLY: NP + 1 Gaussian planes, subtracted when a row is consumed */
         const int    xl = max(x - 1, 0), xr = min(x + 1, w - 1);
         RowRed<NP>   A, B, C;
         float        vB[NP], smx[NP], smn[NP];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         auto fetch_row = [&](int y, float* raw) {
             const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
-            for (int z = 0; z < NP; z++) {
+            for (int z = 0; z < NRAW / 3; z++) {
 #ifdef DET_NO_LOAD /* timing probe (tools/desc_variants.sh): results are wrong */
                 raw[3 * z + 0] = (float)(y * 3 + z) * 1e-3f;
                 raw[3 * z + 1] = (float)(xl + z) * 1e-3f;
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         auto reduce_row = [&](const float* raw, RowRed<NP>& R, float* v, float* sx_, float* sn_) {
 #pragma unroll
             for (int z = 0; z < NP; z++) {
-                const float c = raw[3 * z + 0];
-                const float l = raw[3 * z + 1];
-                const float r = raw[3 * z + 2];
+                const float c = FLY ? raw[3 * z + 3] - raw[3 * z + 0] : raw[3 * z + 0];
+                const float l = FLY ? raw[3 * z + 4] - raw[3 * z + 1] : raw[3 * z + 1];
+                const float r = FLY ? raw[3 * z + 5] - raw[3 * z + 2] : raw[3 * z + 2];
                 v[z] = c;
                 sx_[z] = fmaxf(l, r);
                 sn_[z] = fminf(l, r);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             }
         };
         {
-            float tv[NP], ts[NP], tn[NP], ra[3 * NP], rb[3 * NP];
+            float tv[NP], ts[NP], tn[NP], ra[NRAW], rb[NRAW];
             fetch_row(yb - 1, ra);
             fetch_row(yb, rb);
             reduce_row(ra, A, tv, ts, tn);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
         };
         if (SLOW) {
             for (int y = yb; y <= ye; y++) {
-                float q[3 * NP];
+                float q[NRAW];
                 fetch_row(y + 1, q);
                 step(y, q);
                 if (n_buf > QCAP - 64 * LEVELS) n_buf = flush(n_buf);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             flush(n_buf);
         } else {
             for (int y0 = yb; y0 <= ye; y0 += DET_G) {
-                float q[DET_G][3 * NP];
+                float q[DET_G][NRAW];
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + k + 1, ye + 1), q[k]);
 #ifdef DET_NO_STEP /* timing probe: loads only */
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
 #pragma unroll
                 for (int k = 0; k < DET_G; k++)
 #pragma unroll
-                    for (int j = 0; j < 3 * NP; j++) acc += q[k][j];
+                    for (int j = 0; j < NRAW; j++) acc += q[k][j];
                 if (acc == 1.2345e30f) overflow = true;
 #else
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
  * to their octave's list with ONE returning global atomic per workgroup, octave and step (LDS counters
  * gather the four waves first) -- the same hot-counter limit as in the detection kernel.
  */
-template <int MODE>
+template <int MODE, bool FLY>
 __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
                                                 SiftConsts sc, Counters* __restrict__ ct,
                                                 const int2* __restrict__ cand, int cand_cap,
@@ -520,15 +520,15 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
                 const int  x = cd.x & 0xffff, y = cd.x >> 16, level = cd.y & 0xff;
                 o = cd.y >> 8;
                 const OctDesc* od = &pdp->o[o];
-                DogView        dog;
-                dog.base = arena + od->dog_off;
+                DogView<FLY>   dog;
+                dog.base = arena + (FLY ? od->data_off : od->dog_off);
                 dog.ps = od->plane_stride;
                 dog.w = od->w;
                 dog.h = od->h;
                 dog.pitch = od->pitch;
                 dog.nl = L - 1;
                 const float val = dog.raw(x, y, level);
-                found = refine<MODE>(dog, sc, x, y, level, val, L - 1, ec);
+                found = refine<MODE, FLY>(dog, sc, x, y, level, val, L - 1, ec);
             }
             /* wave64 compaction per octave (replaces extrema_count, s_extrema.cu:22-44), wave -> workgroup in LDS */
             unsigned long long todo = __ballot(found);
@@ -571,8 +571,13 @@ static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
     switch (pd.levels) {
 #define PS_LV(N)                                                                                              \
     case N:                                                                                                   \
-        hipLaunchKernelGGL((k_detect<MODE, N, false>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
-        hipLaunchKernelGGL((k_detect<MODE, N, true>), sgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+        if (pd.dog_fly) {                                                                                     \
+            hipLaunchKernelGGL((k_detect<MODE, N, false, true>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+            hipLaunchKernelGGL((k_detect<MODE, N, true, true>), sgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+        } else {                                                                                              \
+            hipLaunchKernelGGL((k_detect<MODE, N, false, false>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+            hipLaunchKernelGGL((k_detect<MODE, N, true, false>), sgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+        }                                                                                                     \
         break;
         PS_LV(2) PS_LV(3) PS_LV(4) PS_LV(5) PS_LV(6) PS_LV(7) PS_LV(8) PS_LV(9)
 #undef PS_LV
@@ -588,15 +593,24 @@ hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
     switch (sc.sift_mode) {
     case POPSIFT_HIP_SIFT_OPENCV:
         launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
-        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+        if (pd.dog_fly)
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+        else
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, false>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     case POPSIFT_HIP_SIFT_VLFEAT:
         launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
-        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+        if (pd.dog_fly)
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+        else
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, false>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     default:
         launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
-        hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+        if (pd.dog_fly)
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+        else
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, false>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         break;
     }
     return hipGetLastError();

@@ -33,6 +33,7 @@ int        blur_tile_h(int w, int h); /* 32 or 64 rows, by plane size */
 hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s);
 
 /* extrema.hip */
+hipError_t launch_dog_plane(float* dog, const float* upper, const float* lower, size_t n, hipStream_t s); /* debug / test downloads */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */
 hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, int2* cand,
                           int cand_cap, int* ovf, InitExt* iext, hipStream_t s);

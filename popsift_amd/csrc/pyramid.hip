@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                     if (acc.x == 1.2345e30f) a.dst[0] = acc.y + old[g][o].x;
 #else
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
-                    if (MODE == 0)
+                    if (MODE == 0 && a.dog)
                         __builtin_nontemporal_store(acc - old[g][o], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
 #endif
                     /* the next octave's level 0 takes pixel (2x, 2y): its width is ceil(w / 2), so 2x <= w - 1 always
@@ -392,6 +392,18 @@ hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
 }
 
 }  // namespace
+
+/* make_dog (s_pyramid_build.cu:74-92) for one plane, on demand: the pipeline itself no longer stores DoG planes */
+__global__ void k_dog_plane(float* __restrict__ dog, const float* __restrict__ upper, const float* __restrict__ lower, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dog[i] = upper[i] - lower[i];
+}
+
+hipError_t launch_dog_plane(float* dog, const float* upper, const float* lower, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dog_plane, dim3(2048), dim3(256), 0, s, dog, upper, lower, n);
+    return hipGetLastError();
+}
 
 int blur_tile_w() { return TW; }
 

@@ -31,6 +31,8 @@ struct PyrDesc {
     int     levels; /* DoG search levels */
     int     L;      /* levels + 3        */
     int     total_tiles;
+    int     dog_fly; /* 1: DoG planes are not stored; detection / refinement subtract the Gaussian planes they load */
+    int     pad_;
     OctDesc o[PS_MAX_OCT];
 };
 

@@ -255,10 +255,11 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
     pd.n_oct = n_oct;
     pd.levels = c->levels;
     pd.L = c->L;
-    /* POPSIFT_HIP_DOG_FLY=1: the blur kernel does not store DoG planes; detection and refinement subtract the Gaussian
-     * planes they load (bit-identical results, 33 % fewer bytes per level launch -- but refinement's scattered
-     * neighbourhood reads double, which for now eats the gain: off by default) */
-    static const int dog_fly = []() { const char* e = getenv("POPSIFT_HIP_DOG_FLY"); return e ? atoi(e) : 0; }();
+    /* DoG planes are not stored: detection and refinement subtract the Gaussian planes they load -- the same f32
+     * subtraction make_dog does (s_pyramid_build.cu:74-92), so results are bit-identical, with a third fewer bytes per
+     * level launch and an octave-0 working set that fits the last-level cache.  POPSIFT_HIP_DOG_FLY=0 restores the
+     * stored planes (tests compare the two paths). */
+    static const int dog_fly = []() { const char* e = getenv("POPSIFT_HIP_DOG_FLY"); return e ? atoi(e) : 1; }();
     pd.dog_fly = dog_fly ? 1 : 0;
     size_t total = 0;
     int    ow = bw, oh = bh, tiles = 0;

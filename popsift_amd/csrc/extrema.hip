@@ -107,6 +107,13 @@ __device__ __forceinline__ int f2i_sat(float f)
     return (int)f;
 }
 
+/* slot of neighbour (dx, dy) in refine()'s value cache: centre, +x, -x, +y, -y, then the four diagonals */
+__device__ constexpr int nb_index(int dx, int dy)
+{
+    return (dx == 0 && dy == 0) ? 0 : (dx == 1 && dy == 0) ? 1 : (dx == -1 && dy == 0) ? 2 : (dx == 0 && dy == 1) ? 3
+         : (dx == 0 && dy == -1) ? 4 : (dx == -1 && dy == -1) ? 5 : (dx == -1 && dy == 1) ? 6 : (dx == 1 && dy == -1) ? 7 : 8;
+}
+
 /* s_extrema.cu:300-504 (after the contrast + 26-neighbour tests) */
 template <int MODE, bool FLY>
 __device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int y, int level, float val,
@@ -119,9 +126,41 @@ __device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int
     int       iter = 0;
     constexpr int MAX_ITERATIONS = 5;
 
-#define R(dx, dy, dz) dog.at(nx + (dx), ny + (dy), nz + (dz))
+    /* FLY: the 19 DoG values of an iteration come from 28 Gaussian values fetched once (levels nz-1 .. nz+2: the
+     * centre cross on the outer two, the full 3x3 on the inner two) instead of 2 x 19 loads; same clamping as
+     * DogView::at. */
+    float D[3][9];
+#define R(dx, dy, dz) (FLY ? D[(dz) + 1][nb_index(dx, dy)] : dog.at(nx + (dx), ny + (dy), nz + (dz)))
     do {
         iter++;
+        if (FLY) {
+            const int    xs[3] = {clampi(nx - 1, 0, width - 1), clampi(nx, 0, width - 1), clampi(nx + 1, 0, width - 1)};
+            const int    ys[3] = {clampi(ny - 1, 0, height - 1), clampi(ny, 0, height - 1), clampi(ny + 1, 0, height - 1)};
+            /* nz is 1 .. nl-1 here (the PopSift mode may step up to nl-1, where the z+1 plane clamps back onto
+             * plane nl-1 as in DogView::at) */
+            const int     zc = clampi(nz, 1, dog.nl - 1);
+            const bool    top = (zc + 1 > dog.nl - 1);
+            const float*  g = dog.base + (int64_t)(zc - 1) * dog.ps;
+            const int64_t ps3 = (top ? 2 : 3) * dog.ps; /* Gaussian level zc+2 does not exist when top */
+            constexpr int DX[9] = {0, 1, -1, 0, 0, -1, -1, 1, 1}, DY[9] = {0, 0, 0, 1, -1, -1, 1, -1, 1};
+            float         g0[5], g1[9], g2[9], g3[5];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int64_t off = (int64_t)ys[DY[i] + 1] * dog.pitch + xs[DX[i] + 1];
+                if (i < 5) g0[i] = g[off];
+                g1[i] = g[dog.ps + off];
+                g2[i] = g[2 * dog.ps + off];
+                if (i < 5) g3[i] = g[ps3 + off];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                D[1][i] = g2[i] - g1[i];
+                if (i < 5) {
+                    D[0][i] = g1[i] - g0[i];
+                    D[2][i] = top ? D[1][i] : g3[i] - g2[i];
+                }
+            }
+        }
         const float x2y1z1 = R(1, 0, 0), x0y1z1 = R(-1, 0, 0);
         const float x1y2z1 = R(0, 1, 0), x1y0z1 = R(0, -1, 0);
         const float x1y1z2 = R(0, 0, 1), x1y1z0 = R(0, 0, -1);

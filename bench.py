@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per step per GPU (one step = one batch)")
     ap.add_argument("--contexts", type=int, default=16, help="extraction contexts (images in flight) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="timed loop only: no roofline / host-to-host / CPU legs (A/B runs)")
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context roofline pass (the command profiles/ *_roofline_pass* was taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
@@ -180,7 +181,10 @@ def main():
     value = mpix / elapsed
 
     extra = {}
-    if rank == 0:
+    if rank == 0 and args.quick:
+        print(json.dumps({"value": round(value, 2), "unit": "Mpix/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "steps": args.steps, "quick": True}), flush=True)
+    elif rank == 0:
         # ---- single-image device latency (hipEvents, first to last kernel) -------------
         c0 = ctxs[0]
         lat = []

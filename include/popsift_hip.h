@@ -68,7 +68,9 @@ typedef struct popsift_hip_params {
     int32_t filter_grid_size;    /* 2: the grid filter works on size x size cells */
     int32_t filter_max_extrema;  /* -1 = grid filter off (s_orientation.cu:362)  */
     int32_t filter_sorting;      /* POPSIFT_HIP_FILTER_*                         */
-    int32_t reserved[3];
+    int32_t store_dog;           /* 0 (default): DoG planes are formed on the fly by their consumers (bit-identical);
+                                  * 1: stored as the reference does (s_pyramid_build.cu:74-92), for stage tests     */
+    int32_t reserved[2];
 } popsift_hip_params;
 
 /* POD mirror of popsift::Feature (features.h:22-34): the four Descriptor*
@@ -225,12 +227,21 @@ int popsift_hip_set_profile(popsift_hip_ctx* ctx, int profile);
  * sift_octave.cu:110-187).  kind: 0 = Gaussian plane, 1 = DoG plane. */
 int popsift_hip_octave_dims(const popsift_hip_ctx* ctx, int octave, int* w, int* h);
 int popsift_hip_download_plane(popsift_hip_ctx* ctx, int octave, int kind, int level, float* out);
-/* Overwrite a plane (stage isolation in tests), then re-run later stages. */
+/* Overwrite a plane (stage isolation in tests), then re-run later stages.  kind = 1 needs params.store_dog = 1
+ * (POPSIFT_HIP_ERR_STATE otherwise: the consumers form DoG values from the Gaussian planes). */
 int popsift_hip_upload_plane(popsift_hip_ctx* ctx, int octave, int kind, int level, const float* in);
 /* Initial extrema of the last image, all octaves, in device compaction order. */
 int popsift_hip_download_extrema(popsift_hip_ctx* ctx, popsift_hip_extremum* out, size_t cap, int* n);
 /* Re-run extrema + orientation + descriptors on the planes currently in memory. */
 int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
+/* Test switches of one context (no environment variables are read by this library).  Set them before the first
+ * submit: DET_QCAP = candidate-queue entries the fast detection pass may use (small values force strips into the
+ * slow pass); CAND_CAP / OHIST_CAP = initial capacity of the candidate buffer / of the orientation-histogram buffer
+ * (small values exercise the grow-and-rerun path of popsift_hip_wait); FAIL_ALLOC = n: the n-th device allocation
+ * of this context from now on fails with POPSIFT_HIP_ERR_OOM (0 = off). */
+enum { POPSIFT_HIP_DEBUG_DET_QCAP = 1, POPSIFT_HIP_DEBUG_CAND_CAP = 2, POPSIFT_HIP_DEBUG_OHIST_CAP = 3,
+       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4 };
+int popsift_hip_debug_set(popsift_hip_ctx* ctx, int what, int value);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpopsift_hip.so")
+# POPSIFT_HIP_LIB: load another build of the SAME library (tools/build_variants.sh experiment builds); never a fallback
+LIB_PATH = os.environ.get("POPSIFT_HIP_LIB") or os.path.join(_HERE, "libpopsift_hip.so")
 
 MAX_OCTAVES = 20
 ORI_MAX = 4
@@ -34,7 +35,7 @@ class Params(C.Structure):
         ("norm_mode", C.c_int32), ("norm_multi", C.c_int32), ("max_extrema", C.c_int32),
         ("assume_initial_blur", C.c_int32), ("initial_blur", C.c_float),
         ("filter_grid_size", C.c_int32), ("filter_max_extrema", C.c_int32), ("filter_sorting", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("store_dog", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -109,7 +110,9 @@ SYMBOLS = [
     ("popsift_hip_upload_plane", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     ("popsift_hip_download_extrema", C.c_int, [_vp, _vp, C.c_size_t, _ip]),
     ("popsift_hip_rerun_keypoint_stages", C.c_int, [_vp]),
+    ("popsift_hip_debug_set", C.c_int, [_vp, C.c_int, C.c_int]),
 ]
+DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC = 1, 2, 3, 4
 
 _lib = None
 
@@ -323,4 +326,9 @@ class Context:
 
     def rerun_keypoint_stages(self):
         self._chk(lib().popsift_hip_rerun_keypoint_stages(self._h), "rerun_keypoint_stages")
+        return self
+
+    def debug_set(self, what, value):
+        """popsift_hip_debug_set: test switches (DEBUG_*), before the first submit"""
+        self._chk(lib().popsift_hip_debug_set(self._h, what, value), "popsift_hip_debug_set")
         return self

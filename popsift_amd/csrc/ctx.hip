@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,14 +71,20 @@ struct popsift_hip_ctx {
     float*  d_arena = nullptr;
     size_t  arena_cap = 0; /* floats */
     PyrDesc pd{};
-    int      ori_blocks = 8192, desc_blocks = 16384; /* grid-stride workgroups of the keypoint kernels */
+    int      kp_waves = 65536; /* launch size of the keypoint kernels in waves (8 per wave slot of the device) */
+    int      det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
+    int      cand_cap_init = 1 << 20;
+    int      ohist_cap_init = 0;
     InitExt* d_iext = nullptr;
     InitExt* d_iext2 = nullptr;      /* grid filter output (filter enabled only) */
     FilterState* d_fstate = nullptr;
     int*     d_fhist = nullptr;
     Ext*     d_ext = nullptr;
+    float*   d_ohist = nullptr; /* raw orientation histograms, 36 floats per extremum (k_orientation -> k_scan_local) */
+    size_t   ohist_cap = 0;     /* extrema */
     popsift_hip_feature* d_feats = nullptr;
-    size_t   ext_cap = 0; /* entries in d_iext/d_ext/d_feats */
+    size_t   ext_cap = 0; /* entries every one of d_iext/d_ext/d_feats(/d_iext2) holds */
+    size_t   iext_cap = 0, iext2_cap = 0, extrec_cap = 0, feats_cap = 0;
     int*     d_map = nullptr;
     float2*  d_rot = nullptr; /* (cos, sin) of every descriptor's orientation, correctly rounded (k_scan_apply) */
     float*   d_desc = nullptr;
@@ -94,6 +101,7 @@ struct popsift_hip_ctx {
     size_t    partial_cap = 0;
 
     /* profiling */
+    int                    fail_alloc_in = 0; /* test hook (popsift_hip_debug_fail_alloc): the n-th device allocation from now fails */
     int                    profile = 0;
     std::vector<EventPair> blur_events;
     size_t                 blur_events_used = 0;
@@ -180,10 +188,7 @@ void init_tables(popsift_hip_ctx* c)
     sc.desc_mode = p.desc_mode;
     sc.filter_max = p.filter_max_extrema;
     sc.filter_mode = p.filter_sorting;
-    {
-        const char* e = getenv("POPSIFT_HIP_DET_QCAP"); /* test hook: force strips into the slow detection pass */
-        sc.det_qcap = e ? std::max(atoi(e), 0) : (1 << 30);
-    }
+    sc.det_qcap = c->det_qcap;
 }
 
 /* PopSift::private_init, popsift.cpp:89-120 */
@@ -198,6 +203,16 @@ void plan_dims(const popsift_hip_ctx* c, int w, int h, int octaves_cfg, int* n_o
     *bh = (int)ceilf(h * scaleFactor);
 }
 
+/* every device allocation of a context goes through here, so that tests can make the n-th one fail */
+hipError_t ctx_malloc(popsift_hip_ctx* c, void** p, size_t bytes)
+{
+    if (c->fail_alloc_in > 0 && --c->fail_alloc_in == 0) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, bytes);
+}
+
 template <typename T>
 int grow(popsift_hip_ctx* c, T** ptr, size_t* cap, size_t need)
 {
@@ -205,7 +220,7 @@ int grow(popsift_hip_ctx* c, T** ptr, size_t* cap, size_t need)
     if (*ptr) HIP_TRY(c, hipFree(*ptr));
     *ptr = nullptr;
     *cap = 0;
-    HIP_TRY(c, hipMalloc((void**)ptr, need * sizeof(T)));
+    HIP_TRY(c, ctx_malloc(c, (void**)ptr, need * sizeof(T)));
     *cap = need;
     return 0;
 }
@@ -220,10 +235,21 @@ int ensure_desc_cap(popsift_hip_ctx* c, int need)
     c->d_map = nullptr;
     c->d_rot = nullptr;
     c->desc_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_desc, (size_t)need * 128 * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_map, (size_t)need * sizeof(int)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_rot, (size_t)need * sizeof(float2)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_desc, (size_t)need * 128 * sizeof(float)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_map, (size_t)need * sizeof(int)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_rot, (size_t)need * sizeof(float2)));
     c->desc_cap = need;
+    return 0;
+}
+
+int ensure_ohist_cap(popsift_hip_ctx* c, size_t need)
+{
+    if (need <= c->ohist_cap) return 0;
+    if (c->d_ohist) HIP_TRY(c, hipFree(c->d_ohist));
+    c->d_ohist = nullptr;
+    c->ohist_cap = 0;
+    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_ohist, need * PS_ORI_NBINS * sizeof(float)));
+    c->ohist_cap = need;
     return 0;
 }
 
@@ -233,34 +259,43 @@ int ensure_cand_cap(popsift_hip_ctx* c, int need)
     if (c->d_cand) HIP_TRY(c, hipFree(c->d_cand));
     c->d_cand = nullptr;
     c->cand_cap = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_cand, (size_t)need * sizeof(int2)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_cand, (size_t)need * sizeof(int2)));
     c->cand_cap = need;
     return 0;
 }
 
-/* Pyramid::Pyramid / resetDimensions: sizes for this image, grow-only arena */
+/* Pyramid::Pyramid / resetDimensions: sizes for this image, grow-only arena.
+ * Failure-safe: the context forgets its geometry before anything is freed and commits the new one only after every
+ * allocation and the upload of the device copy have been issued, so a submit after a failed one (ERR_OOM is a
+ * recoverable status of this ABI) never finds sizes that describe buffers which no longer exist. */
 int prepare_geometry(popsift_hip_ctx* c, int w, int h)
 {
     /* same size as the previous image of this context: planes, descriptors and the device copy of the geometry stand */
     if (c->have_image && w == c->in_w && h == c->in_h && c->pd.n_oct > 0) return 0;
     int n_oct, bw, bh;
     plan_dims(c, w, h, c->frozen_octaves, &n_oct, &bw, &bh);
-    c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */
     if (bw < 1 || bh < 1) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image is empty");
     /* candidates pack (x, y) into 16 bits each; the reference's Plane2D uses short dims too (plane_2d.h:257) */
     if (bw > 32767 || bh > 32767) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image exceeds 32767 pixels per side");
+    if (c->sc.filter_max > 0 && !filter_supported(n_oct, c->sc.max_extrema, c->sc.grid_size))
+        return fail(c, POPSIFT_HIP_ERR_INVALID, "grid filter: grid size > 64 or octaves * max_extrema >= 2^25");
+    c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */
 
-    PyrDesc& pd = c->pd;
+    c->in_w = c->in_h = 0;
+    c->have_image = false;
+    c->pd.n_oct = 0;
+
+    PyrDesc pd;
     memset(&pd, 0, sizeof(pd));
     pd.n_oct = n_oct;
     pd.levels = c->levels;
     pd.L = c->L;
-    /* DoG planes are not stored: detection and refinement subtract the Gaussian planes they load -- the same f32
-     * subtraction make_dog does (s_pyramid_build.cu:74-92), so results are bit-identical, with a third fewer bytes per
-     * level launch and an octave-0 working set that fits the last-level cache.  POPSIFT_HIP_DOG_FLY=0 restores the
-     * stored planes (tests compare the two paths). */
-    static const int dog_fly = []() { const char* e = getenv("POPSIFT_HIP_DOG_FLY"); return e ? atoi(e) : 1; }();
-    pd.dog_fly = dog_fly ? 1 : 0;
+    /* DoG planes are not stored (params.store_dog = 0): detection and refinement subtract the Gaussian planes they
+     * load -- the same f32 subtraction make_dog does (s_pyramid_build.cu:74-92), so results are bit-identical, with a
+     * third fewer bytes per level launch and an octave-0 working set that fits the last-level cache.  The arena then
+     * holds L planes per octave plus ONE scratch plane (the size of octave 0's) into which the debug download forms a
+     * DoG plane on demand; with store_dog = 1 it holds the reference's 2L-1 planes per octave. */
+    pd.dog_fly = c->p.store_dog ? 0 : 1;
     size_t total = 0;
     int    ow = bw, oh = bh, tiles = 0;
     for (int o = 0; o < n_oct; o++) {
@@ -271,48 +306,55 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
         od.plane_stride = (int64_t)od.pitch * oh;
         od.tile_begin = tiles;
         tiles += extrema_units(ow, oh);
-        total += (size_t)od.plane_stride * (size_t)(2 * c->L - 1);
+        total += (size_t)od.plane_stride * (size_t)(pd.dog_fly ? c->L : 2 * c->L - 1);
         ow = (int)ceilf(ow / 2.0f); /* sift_pyramid.cu:132-133 */
         oh = (int)ceilf(oh / 2.0f);
     }
+    if (pd.dog_fly) total += (size_t)pd.o[0].plane_stride;
     pd.total_tiles = tiles;
     if (int rc = grow(c, &c->d_arena, &c->arena_cap, total)) return rc;
     float* p = c->d_arena;
+    float* scratch = c->d_arena + (total - (size_t)pd.o[0].plane_stride);
     for (int o = 0; o < n_oct; o++) {
         OctDesc& od = pd.o[o];
         od.data = p;
         od.data_off = p - c->d_arena;
         p += od.plane_stride * c->L;
-        od.dog = p;
-        od.dog_off = p - c->d_arena;
-        p += od.plane_stride * (c->L - 1);
+        if (pd.dog_fly) {
+            od.dog = scratch; /* download_plane(kind = 1) only */
+            od.dog_off = scratch - c->d_arena;
+        } else {
+            od.dog = p;
+            od.dog_off = p - c->d_arena;
+            p += od.plane_stride * (c->L - 1);
+        }
     }
     const size_t need_ext = (size_t)n_oct * (size_t)c->sc.max_extrema;
     if (need_ext > c->ext_cap) {
-        size_t cap0 = c->ext_cap, cap1 = c->ext_cap, cap2 = c->ext_cap;
-        if (int rc = grow(c, &c->d_iext, &cap0, need_ext)) return rc;
-        if (int rc = grow(c, &c->d_ext, &cap1, need_ext)) return rc;
-        if (int rc = grow(c, &c->d_feats, &cap2, need_ext)) return rc;
-        if (c->sc.filter_max > 0) {
-            size_t cap3 = c->ext_cap;
-            if (int rc = grow(c, &c->d_iext2, &cap3, need_ext)) return rc;
-        }
+        /* each buffer keeps its own capacity: a failed grow leaves the others consistent */
+        c->ext_cap = 0;
+        if (int rc = grow(c, &c->d_iext, &c->iext_cap, need_ext)) return rc;
+        if (int rc = grow(c, &c->d_ext, &c->extrec_cap, need_ext)) return rc;
+        if (int rc = grow(c, &c->d_feats, &c->feats_cap, need_ext)) return rc;
+        if (c->sc.filter_max > 0)
+            if (int rc = grow(c, &c->d_iext2, &c->iext2_cap, need_ext)) return rc;
         c->ext_cap = need_ext;
     }
-    if (c->sc.filter_max > 0 && !filter_supported(n_oct, c->sc.max_extrema, c->sc.grid_size))
-        return fail(c, POPSIFT_HIP_ERR_INVALID, "grid filter: grid size > 64 or octaves * max_extrema >= 2^25");
     if (int rc = grow(c, &c->d_partial, &c->partial_cap, need_ext / scan_chunk() + 2)) return rc;
     /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
         return rc;
-    {
-        const char* e = getenv("POPSIFT_HIP_CAND_CAP"); /* test hook: start small to exercise the regrow path */
-        if (int rc = ensure_cand_cap(c, e ? std::max(atoi(e), DET_SUBQ) : (1 << 20))) return rc;
-    }
+    if (int rc = ensure_cand_cap(c, std::max(c->cand_cap_init, DET_SUBQ))) return rc;
+    /* orientation histograms: 2 * max_extrema extrema to start with (all octaves together seldom exceed one octave's
+     * cap); finish() grows the buffer and re-runs the keypoint stages when an image has more */
+    if (int rc = ensure_ohist_cap(c, c->ohist_cap_init > 0 ? (size_t)c->ohist_cap_init
+                                                             : std::min(need_ext, (size_t)2 * c->sc.max_extrema)))
+        return rc;
     if (int rc = grow(c, &c->d_ovf, &c->ovf_cap, (size_t)tiles + 1)) return rc;
     /* the stream is idle here (submit drains the previous image first), so h_pd is free to reuse */
-    *c->h_pd = c->pd;
+    *c->h_pd = pd;
     HIP_TRY(c, hipMemcpyAsync(c->d_pd, c->h_pd, sizeof(PyrDesc), hipMemcpyHostToDevice, c->stream));
+    c->pd = pd;
     c->in_w = w;
     c->in_h = h;
     c->rep.num_octaves = n_oct;
@@ -409,11 +451,12 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
         /* Pyramid::orientation's filter hook (s_orientation.cu:353-367); the 10 % test is taken on the device */
         HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->d_ct, c->d_iext, c->d_iext2, c->d_fstate, c->d_fhist, c->stream));
     }
-    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ext, c->ori_blocks, c->stream));
+    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->kp_waves,
+                                  c->stream));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
-    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, c->d_ext, c->d_partial, std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_feats, c->desc_cap,
-                           c->stream));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->desc_blocks,
+    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->d_ext, c->d_partial,
+                           std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_feats, c->desc_cap, c->stream));
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->kp_waves,
                                   c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     return 0;
@@ -435,9 +478,10 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
     if (!on_device) {
         size_t cap = c->input_cap;
         char*  buf = (char*)c->d_input;
-        if (int rc = grow(c, &buf, &cap, (size_t)w * h * esz)) return rc;
-        c->d_input = buf;
+        const int rc_in = grow(c, &buf, &cap, (size_t)w * h * esz);
+        c->d_input = buf; /* also after a failed grow, which has freed the old buffer */
         c->input_cap = cap;
+        if (rc_in) return rc_in;
         /* Like Image::load (s_image.cu:71-79) the caller's buffer is copied into pinned memory before
          * this call returns: the caller may free or reuse it immediately (popsift.cpp:245-247), and an
          * async copy straight from pageable memory would read it later. */
@@ -474,15 +518,20 @@ int finish(popsift_hip_ctx* c)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const bool desc_short = c->h_ct->ori_total > c->desc_cap;
         int qmax = 0;
-        for (int q = 0; q < DET_SUBQ; q++) qmax = std::max(qmax, c->h_ct->qcnt[q]);
+        for (int q = 0; q < DET_SUBQ; q++) qmax = std::max(qmax, c->h_ct->qcnt[q].n);
         const bool cand_short = qmax > c->cand_cap / DET_SUBQ;
-        if (!desc_short && !cand_short) break;
+        long       ext_sum = 0; /* ext_total is written by the scan, which may have run on a clipped list: recount */
+        for (int o = 0; o < c->pd.n_oct; o++) ext_sum += std::min(c->h_ct->ext_ct[o], c->sc.max_extrema);
+        const bool hist_short = (size_t)ext_sum > c->ohist_cap;
+        if (!desc_short && !cand_short && !hist_short) break;
         /* more candidates / descriptors than the buffers hold (the reference reallocates between
          * stages, sift_pyramid.cu:179-209): grow and redo the keypoint stages of this image */
         if (desc_short)
             if (int rc = ensure_desc_cap(c, c->h_ct->ori_total + c->h_ct->ori_total / 8 + 1024)) return rc;
         if (cand_short)
             if (int rc = ensure_cand_cap(c, DET_SUBQ * (qmax + qmax / 8 + 64))) return rc;
+        if (hist_short)
+            if (int rc = ensure_ohist_cap(c, (size_t)ext_sum + (size_t)ext_sum / 8 + 1024)) return rc;
         if (int rc = enqueue_keypoint_stages(c)) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     }
@@ -538,7 +587,7 @@ int plane_ptr(popsift_hip_ctx* c, int octave, int kind, int level, float** p, co
     if (kind == 0 && level < c->L)
         *p = od.data + level * od.plane_stride;
     else if (kind == 1 && level < c->L - 1)
-        *p = od.dog + level * od.plane_stride;
+        *p = c->pd.dog_fly ? od.dog : od.dog + level * od.plane_stride; /* not stored: the scratch plane */
     else
         return fail(c, POPSIFT_HIP_ERR_INVALID, "bad plane kind/level");
     *odp = &od;
@@ -656,11 +705,17 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
     c->levels = std::max(2, p->levels); /* popsift.cpp:71 */
     c->L = c->levels + 3;
     c->frozen_octaves = p->octaves;
-    if (const char* e = getenv("POPSIFT_HIP_ORI_BLOCKS")) c->ori_blocks = std::max(atoi(e), 64);   /* tuning knobs */
-    if (const char* e = getenv("POPSIFT_HIP_DESC_BLOCKS")) c->desc_blocks = std::max(atoi(e), 64);
     init_tables(c);
     int rc = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
+        {
+            int cus = 0;
+            HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+#ifndef KP_GRID_MULT
+#define KP_GRID_MULT 1
+#endif
+            c->kp_waves = std::max(cus, 8) * 32 * 8 * KP_GRID_MULT; /* a multiple of 32 */
+        }
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
         HIP_TRY(c, hipEventCreate(&c->ev_end));
@@ -702,6 +757,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_fstate) (void)hipFree(c->d_fstate);
     if (c->d_fhist) (void)hipFree(c->d_fhist);
     if (c->d_ext) (void)hipFree(c->d_ext);
+    if (c->d_ohist) (void)hipFree(c->d_ohist);
     if (c->d_feats) (void)hipFree(c->d_feats);
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_rot) (void)hipFree(c->d_rot);
@@ -1062,6 +1118,8 @@ int popsift_hip_upload_plane(popsift_hip_ctx* c, int octave, int kind, int level
     float*         p = nullptr;
     const OctDesc* od = nullptr;
     if (!in) return POPSIFT_HIP_ERR_INVALID;
+    if (c && c->have_image && kind == 1 && c->pd.dog_fly)
+        return fail(c, POPSIFT_HIP_ERR_STATE, "DoG planes are not stored (params.store_dog = 0): upload Gaussian planes");
     if (int rc = plane_ptr(c, octave, kind, level, &p, &od)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1096,6 +1154,26 @@ int popsift_hip_download_extrema(popsift_hip_ctx* c, popsift_hip_extremum* out, 
         }
     }
     return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    switch (what) {
+    case POPSIFT_HIP_DEBUG_DET_QCAP:
+        c->det_qcap = c->sc.det_qcap = std::max(value, 0);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_CAND_CAP:
+        c->cand_cap_init = std::max(value, DET_SUBQ);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_OHIST_CAP:
+        c->ohist_cap_init = std::max(value, 1);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_FAIL_ALLOC:
+        c->fail_alloc_in = std::max(value, 0);
+        return POPSIFT_HIP_OK;
+    }
+    return fail(c, POPSIFT_HIP_ERR_INVALID, "unknown debug switch %d", what);
 }
 
 int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* c)

@@ -372,9 +372,11 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             if (n == 0) return 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int subq = blockIdx.x & (DET_SUBQ - 1), seg = cand_cap / DET_SUBQ;
+            /* the sub-queue is the strip's cell of an 8 x 8 grid over the octave (sift_types.h, Counters::qcnt) */
+            const int urows = (h - 2 + DET_RH - 1) / DET_RH;
+            const int subq = (cy * 8 / urows) * 8 + (sx * 8 / strips), seg = cand_cap / DET_SUBQ;
             int       basei = 0;
-            if (lane == 0) basei = atomicAdd(&ct->qcnt[subq], n);
+            if (lane == 0) basei = atomicAdd(&ct->qcnt[subq].n, n);
             basei = __shfl(basei, 0);
             for (int i = lane; i < n; i += 64)
                 if (basei + i < seg) cand[(size_t)subq * seg + basei + i] = queue[i];
@@ -396,18 +398,7 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
             const float* p = base + (int64_t)y * od.pitch;
 #pragma unroll
             for (int z = 0; z < NRAW / 3; z++) {
-#ifdef DET_NO_LOAD /* timing probe (tools/desc_variants.sh): results are wrong */
-                raw[3 * z + 0] = (float)(y * 3 + z) * 1e-3f;
-                raw[3 * z + 1] = (float)(xl + z) * 1e-3f;
-                raw[3 * z + 2] = (float)(xr - y) * 1e-3f;
-                continue;
-#endif
                 raw[3 * z + 0] = p[z * od.plane_stride + xc];
-#ifdef DET_ONE_LOAD /* timing probe with DET_NO_STEP: one load per row and plane */
-                raw[3 * z + 1] = 0.0f;
-                raw[3 * z + 2] = 0.0f;
-                continue;
-#endif
                 raw[3 * z + 1] = p[z * od.plane_stride + xl];
                 raw[3 * z + 2] = p[z * od.plane_stride + xr];
             }
@@ -489,17 +480,8 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
                 float q[DET_G][NRAW];
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) fetch_row(min(y0 + k + 1, ye + 1), q[k]);
-#ifdef DET_NO_STEP /* timing probe: loads only */
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < DET_G; k++)
-#pragma unroll
-                    for (int j = 0; j < NRAW; j++) acc += q[k][j];
-                if (acc == 1.2345e30f) overflow = true;
-#else
 #pragma unroll
                 for (int k = 0; k < DET_G; k++) step(y0 + k, q[k]);
-#endif
             }
             if (overflow) {
                 /* too many candidates for the queue: leave the whole strip to the SLOW pass */
@@ -528,7 +510,7 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
     const int      L = pdp->L, n_oct = pdp->n_oct;
     const int      seg = cand_cap / DET_SUBQ;
     if (threadIdx.x < 64) {
-        const int steps = (min(ct->qcnt[lane], seg) + 255) >> 8;
+        const int steps = (min(ct->qcnt[lane].n, seg) + 255) >> 8;
         int       incl = steps;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
@@ -546,7 +528,7 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
         for (int w = blockIdx.x; w < n_steps; w += gridDim.x) {
             int q = 0;
             while (s_pref[q + 1] <= w) q++;
-            const int total = min(ct->qcnt[q], seg);
+            const int total = min(ct->qcnt[q].n, seg);
             const int b0 = (w - s_pref[q]) << 8;
             if (threadIdx.x < PS_MAX_OCT) s_cnt[threadIdx.x] = 0;
             __syncthreads();

@@ -39,12 +39,14 @@ hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
                           int cand_cap, int* ovf, InitExt* iext, hipStream_t s);
 
 /* keypoint.hip */
-hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, const Counters* ct, const InitExt* iext,
-                              Ext* ext, int blocks, hipStream_t s);
+/* ohist: 36 floats per extremum (the raw orientation histogram), hist_cap extrema */
+hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, const InitExt* iext,
+                              float* ohist, int hist_cap, int blocks, hipStream_t s);
 int        scan_chunk(); /* extrema per scan workgroup */
-hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
-                       int* map, float2* rot, popsift_hip_feature* feats, int desc_cap, hipStream_t s);
-hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, const Counters* ct, const Ext* ext,
+hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
+                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot,
+                       popsift_hip_feature* feats, int desc_cap, hipStream_t s);
+hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, const Ext* ext,
                               const int* map, const float2* rot, float* desc, int desc_cap, int blocks, hipStream_t s);
 
 /* filter.hip: grid filter between refinement and orientation (s_filtergrid.cu:109-322) */

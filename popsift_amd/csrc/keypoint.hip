@@ -105,6 +105,40 @@ __device__ __forceinline__ float plane_at(const float* pl, int idx)
     return *(const float*)((const char*)pl + (size_t)((unsigned int)idx * 4u));
 }
 
+/*
+ * Work distribution of the keypoint kernels.  Workgroups b and b + 8 share an XCD and its 4 MiB L2 (round-robin
+ * dispatch -- relied on for speed only, never for correctness).  The lists come out of refinement grouped by image
+ * region (extrema.hip: a detection sub-queue is a region, refinement appends one sub-queue batch at a time), so they
+ * are cut into chunks of KP_CHUNK consecutive keypoints, chunk c goes to XCD c mod 8, and the workgroups of an XCD
+ * walk its chunks front to back: the patches of the waves in flight on one XCD overlap, while every XCD still gets
+ * the same mix of levels and octaves (the work per keypoint grows with sigma^2; handing each XCD one contiguous
+ * eighth of a level-major list left the XCD with the coarse levels running 35 % longer than the others).
+ * gridDim.x is a multiple of 8; NW = waves per workgroup.  Position s of XCD x is list element
+ * ((s / KP_CHUNK) * 8 + x) * KP_CHUNK + s % KP_CHUNK.
+ * (Tried and dropped, round 2: resident waves pulling positions from work queues in device memory -- one returning
+ * atomicAdd per keypoint on 32 padded heads, next position requested ahead of time.  592 us against 505 us for the
+ * descriptor kernel, 164 against 106 for orientation: the hardware dispatcher already balances 65536 single-wave
+ * workgroups, and it does so without a memory round trip in the wave's in-order load queue.)
+ */
+#ifndef KP_CHUNK
+#define KP_CHUNK 256
+#endif
+struct XcdSlice {
+    int x, s, step;
+    __device__ __forceinline__ int index() const { return ((s / KP_CHUNK) * 8 + x) * KP_CHUNK + (s % KP_CHUNK); }
+    /* positions whose element lies beyond the list are skipped: later chunks of the same XCD may still be inside */
+    __device__ __forceinline__ bool more(int total) const { return (s / KP_CHUNK) * 8 * KP_CHUNK < total; }
+};
+template <int NW>
+__device__ __forceinline__ XcdSlice xcd_slice()
+{
+    XcdSlice sl;
+    sl.x = blockIdx.x & 7;
+    sl.s = (int)(blockIdx.x >> 3) * NW + (int)(threadIdx.x >> 6);
+    sl.step = (int)(gridDim.x >> 3) * NW;
+    return sl;
+}
+
 /* clamped extrema counts -> exclusive prefix (uniform, <= 20 entries) */
 __device__ __forceinline__ int ext_prefix(const Counters* ct, const SiftConsts& sc, int n_oct, int* ps)
 {
@@ -201,22 +235,35 @@ __device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
 #ifndef KP_NW
 #define KP_NW 1 /* waves per workgroup of k_orientation / k_descriptor: the waves are independent (one keypoint each) */
 #endif
+constexpr int ORI_COPIES = 4; /* private histogram copies by lane: neighbouring pixels often share a bin */
+
+/*
+ * ori_par, first half (s_orientation.cu:60-139): the weighted 36-bin gradient-orientation histogram of one
+ * extremum, one wave per extremum.  The second half -- smoothing, peak interpolation, the four best peaks --
+ * is serial per extremum and runs with one LANE per extremum in k_scan_local (as a wave-wide epilogue here it
+ * was ~350 of the kernel's ~1250 vector instructions per extremum, 62 of them dependent cross-lane shuffles).
+ * The raw histogram crosses in `ohist` (36 floats per extremum).
+ */
 __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __restrict__ pdp,
                                                      const float* __restrict__ arena, SiftConsts sc,
-                                                     const Counters* __restrict__ ct,
-                                                     const InitExt* __restrict__ iext, Ext* __restrict__ ext)
+                                                     Counters* __restrict__ ct,
+                                                     const InitExt* __restrict__ iext, float* __restrict__ ohist,
+                                                     int hist_cap)
 {
     const int n_oct = pdp->n_oct, L = pdp->L;
-    __shared__ fix64 s_hist[KP_NW][PS_ORI_NBINS + 4];
+    __shared__ fix64 s_hist[KP_NW][ORI_COPIES][PS_ORI_NBINS];
     const int        wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    fix64*           hist = s_hist[wave];
+    fix64*           hall = &s_hist[wave][0][0];
+    fix64*           hist = s_hist[wave][lane & (ORI_COPIES - 1)];
 
     __shared__ int ps[PS_MAX_OCT + 1];
     if (threadIdx.x == 0) ext_prefix(ct, sc, n_oct, ps);
     __syncthreads();
-    const int total = ps[n_oct];
+    const int total = min(ps[n_oct], hist_cap);
 
-    for (int g = blockIdx.x * KP_NW + wave; g < total; g += gridDim.x * KP_NW) {
+    for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
+        const int g = sl.index();
+        if (g >= total) continue;
         int o = 0;
         while (o + 1 < n_oct && g >= ps[o + 1]) o++;
         const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - ps[o])];
@@ -225,10 +272,10 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         const int      lvl = min(max(ie.lpos, 0), L - 1);
         const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
 
-        if (lane < PS_ORI_NBINS) hist[lane] = 0ull;
+        for (int k = lane; k < ORI_COPIES * PS_ORI_NBINS; k += 64) hall[k] = 0ull;
         wave_lds_sync();
 
-        const float x = ie.xpos, y = ie.ypos, sig = ie.sigma;
+        const float x = uniformf(ie.xpos), y = uniformf(ie.ypos), sig = uniformf(ie.sigma);
         const float sigw = ORI_WINFACTOR * sig;
         const int   rad = (int)roundf(3.0f * sigw);
         const float factor = -0.5f / (sigw * sigw);
@@ -278,73 +325,83 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         }
         wave_lds_sync();
 
-        /* lanes 0..35 own one bin each; 6 circular box-filter passes (s_orientation.cu:142-160) */
-        const int bin = lane;
-        const int prev = (bin == 0) ? PS_ORI_NBINS - 1 : bin - 1;
-        const int next = (bin >= PS_ORI_NBINS - 1) ? 0 : bin + 1;
-        float     hv = (lane < PS_ORI_NBINS) ? from_fix(hist[lane]) : 0.0f;
+        if (lane < PS_ORI_NBINS) {
+            fix64 acc = 0ull;
 #pragma unroll
-        for (int pass = 0; pass < 6; pass++) {
-            const float hp = __shfl(hv, prev);
-            const float hn = __shfl(hv, next);
-            hv = (hp + hv + hn) / 3.0f;
+            for (int k = 0; k < ORI_COPIES; k++) acc += hall[k * PS_ORI_NBINS + lane];
+            ohist[(size_t)g * PS_ORI_NBINS + lane] = from_fix(acc);
         }
-        const float hp = __shfl(hv, prev);
-        const float hn = __shfl(hv, next);
+        wave_lds_sync();
+    }
+}
 
-        bool        predicate = (lane < PS_ORI_NBINS) && (hv > fmaxf(hp, hn));
+/*
+ * ori_par, second half (s_orientation.cu:142-240), one lane per extremum: six circular box-filter passes, parabolic
+ * peak interpolation, the (at most four) best peaks within 80 % of the best -- BitonicSort::Warp32::sort64
+ * (common/warp_bitonic_sort.h:35-78) becomes four in-register selection rounds, ties to the lower bin.
+ * Everything is indexed statically (fully unrolled), so the 36 bins live in registers.
+ */
+__device__ __forceinline__ int ori_peaks(const float* __restrict__ hsrc, float* angle_out)
+{
+    constexpr int N = PS_ORI_NBINS;
+    float         h[N], t[N];
+#pragma unroll
+    for (int q = 0; q < N / 4; q++) {
+        const float4 v = reinterpret_cast<const float4*>(hsrc)[q];
+        h[4 * q + 0] = v.x;
+        h[4 * q + 1] = v.y;
+        h[4 * q + 2] = v.z;
+        h[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++) {
+#pragma unroll
+        for (int b = 0; b < N; b++) t[b] = (h[b == 0 ? N - 1 : b - 1] + h[b] + h[b == N - 1 ? 0 : b + 1]) / 3.0f;
+#pragma unroll
+        for (int b = 0; b < N; b++) h[b] = (t[b == 0 ? N - 1 : b - 1] + t[b] + t[b == N - 1 ? 0 : b + 1]) / 3.0f;
+    }
+    float refined[N], yval[N];
+#pragma unroll
+    for (int b = 0; b < N; b++) {
+        const int   prev = b == 0 ? N - 1 : b - 1;
+        const float hp = h[prev], hv = h[b], hn = h[b == N - 1 ? 0 : b + 1];
+        bool        predicate = hv > fmaxf(hp, hn);
         const float num = predicate ? 3.0f * hp - 4.0f * hv + 1.0f * hn : 0.0f;
         const float denB = predicate ? 2.0f * (hp - 2.0f * hv + hn) : 1.0f;
         const float newbin = num / denB;
         predicate = (predicate && newbin >= 0.0f && newbin <= 2.0f);
-        const float refined = predicate ? prev + newbin : -1.0f;
-        const float yval = predicate ? -(num * num) / (4.0f * denB) + hp : -INFINITY;
-
-        /* top-4 by yval, ties to the lower bin (replaces BitonicSort::Warp32::sort64) */
-        bool  used = false;
-        float best0 = 0.0f;
-        float my_angle[POPSIFT_HIP_ORI_MAX] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int   angles = 0;
-#pragma unroll
-        for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) {
-            float bv = used ? -INFINITY : yval;
-            int   bi = used ? 128 + lane : lane; /* used lanes lose every tie */
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) {
-                const float ov = __shfl_xor(bv, s);
-                const int   oi = __shfl_xor(bi, s);
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
-            }
-            bi &= 127;
-            if (k == 0) best0 = bv;
-            const float chosen_raw = __shfl(refined, bi);
-            if (lane == bi) used = true;
-            /* yval is sorted descending, so the accepted ones are a prefix: slot k is static */
-            if (bv >= 0.8f * best0) {
-                float chosen_bin = chosen_raw;
-                if (chosen_bin >= PS_ORI_NBINS) chosen_bin -= PS_ORI_NBINS;
-                my_angle[k] = fmaf(F_PI2 * chosen_bin, 1.0f / PS_ORI_NBINS, -F_PI);
-                angles = k + 1;
-            }
-        }
-        if (lane == 0) {
-            Ext e;
-            e.xpos = ie.xpos;
-            e.ypos = ie.ypos;
-            e.lpos = ie.lpos;
-            e.sigma = ie.sigma;
-            e.octave = o;
-            e.num_ori = angles;
-            e.idx_ori = 0;
-#pragma unroll
-            for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) e.orientation[k] = my_angle[k];
-            ext[g] = e;
-        }
-        wave_lds_sync();
+        refined[b] = predicate ? prev + newbin : -1.0f;
+        yval[b] = predicate ? -(num * num) / (4.0f * denB) + hp : -INFINITY;
     }
+    unsigned long long used = 0ull;
+    float              best0 = 0.0f;
+    int                angles = 0;
+#pragma unroll
+    for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) {
+        /* first unused bin, then any later unused bin with a strictly larger value */
+        float bv = 0.0f, br = -1.0f;
+        int   bi = -1;
+#pragma unroll
+        for (int b = 0; b < N; b++) {
+            const bool free_b = !((used >> b) & 1ull);
+            const bool take = free_b && (bi < 0 || yval[b] > bv);
+            bv = take ? yval[b] : bv;
+            br = take ? refined[b] : br;
+            bi = take ? b : bi;
+        }
+        used |= 1ull << bi;
+        if (k == 0) best0 = bv;
+        /* yval is visited in descending order, so the accepted ones are a prefix */
+        if (bv >= 0.8f * best0) {
+            float chosen_bin = br;
+            if (chosen_bin >= N) chosen_bin -= N;
+            angle_out[k] = fmaf(F_PI2 * chosen_bin, 1.0f / N, -F_PI);
+            angles = k + 1;
+        } else {
+            angle_out[k] = 0.0f;
+        }
+    }
+    return angles;
 }
 
 /* ------------------------------------------------------------------- scan */
@@ -371,12 +428,17 @@ __device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConst
 }
 
 __global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                    const Counters* __restrict__ ct, Ext* __restrict__ ext,
-                                                    int* __restrict__ partial)
+                                                    const Counters* __restrict__ ct, const InitExt* __restrict__ iext,
+                                                    const float* __restrict__ ohist, int hist_cap,
+                                                    Ext* __restrict__ ext, int* __restrict__ partial)
 {
     __shared__ int s_wsum[4];
-    const int      total = clamped_total(ct, sc, pdp->n_oct);
-    const int      base = blockIdx.x * SCAN_CHUNK;
+    __shared__ int s_ps[PS_MAX_OCT + 1];
+    const int      n_oct = pdp->n_oct;
+    if (threadIdx.x == 0) ext_prefix(ct, sc, n_oct, s_ps);
+    __syncthreads();
+    const int total = s_ps[n_oct];
+    const int base = blockIdx.x * SCAN_CHUNK;
     if (base >= total) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g0 = base + tid * SCAN_ITEMS;
@@ -384,7 +446,27 @@ __global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ 
     int       self = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        cnt[k] = (g0 + k < total) ? ext[g0 + k].num_ori : 0;
+        const int g = g0 + k;
+        cnt[k] = 0;
+        if (g < total) {
+            /* the second half of ori_par for extremum g, then its Extremum record (sift_extremum.h:40-51) */
+            int o = 0;
+            while (o + 1 < n_oct && g >= s_ps[o + 1]) o++;
+            const InitExt ie = iext[(size_t)o * sc.max_extrema + (g - s_ps[o])];
+            Ext           e;
+            e.xpos = ie.xpos;
+            e.ypos = ie.ypos;
+            e.lpos = ie.lpos;
+            e.sigma = ie.sigma;
+            e.octave = o;
+            e.idx_ori = 0;
+            /* beyond the histogram buffer (the host grows it and re-runs the stages): no orientation */
+            e.num_ori = (g < hist_cap) ? ori_peaks(ohist + (size_t)g * PS_ORI_NBINS, e.orientation) : 0;
+            if (g >= hist_cap)
+                for (int q = 0; q < POPSIFT_HIP_ORI_MAX; q++) e.orientation[q] = 0.0f;
+            ext[g] = e;
+            cnt[k] = e.num_ori;
+        }
         self += cnt[k];
     }
     int incl = self;
@@ -512,49 +594,61 @@ __device__ __forceinline__ float atan2_bins(float y, float x)
 }
 
 /*
- * One wave per (extremum, orientation), four per workgroup, no workgroup
- * barrier.  The reference gives every one of the 16 cells its own warp, which
- * re-computes the gradient of each patch pixel for up to four overlapping
- * cells (s_desc_loop.cu:78-122).  Here each patch pixel is visited once: its
- * gradient is computed once and its contribution is spread to the (at most)
- * 2x2 cells whose unit square contains it -- the same sample set and weights,
- * a different summation order.  The 128-bin histogram lives in LDS (per wave),
- * is normalised in registers and leaves as two coalesced 256 B rows.
+ * One wave per (extremum, orientation), no workgroup barrier.  The reference gives every one of the 16 cells
+ * its own warp, which re-computes the gradient of each patch pixel for up to four overlapping cells
+ * (s_desc_loop.cu:78-122).  Here each patch pixel is visited once: its gradient is computed once and its
+ * contribution is spread to the (at most) 2x2 cells whose unit square contains it -- the same sample set and
+ * weights, a different summation order.  The 128-bin histogram lives in LDS (per wave, fixed point: exact and
+ * order-independent sums), is normalised in registers and leaves as two coalesced 256 B rows.
+ *
+ * LDS atomics set the pace of the first version (rocprofv3, round 2: the LDS was busy 73 % of the kernel's cycles,
+ * 63 % of that bank-conflict cycles): 64 lanes on 64 consecutive pixels of a patch row mostly fall into the same
+ * cell row, a few cells and -- gradients being smooth -- one or two orientation bins, i.e. up to 16 lanes on one
+ * address, and the two private copies sat exactly 1 KiB apart, on the same banks.  Now
+ *   - the wave works as four groups of 16 lanes, each on its own quarter of the sample list (different cell rows),
+ *   - four private copies by lane (neighbouring lanes never share a word),
+ *   - the word of (copy c, cell iy ix, bin b) is c*128 + iy*32 + ((ix + iy) & 3)*8 + ((b + c + 4*(ix & 1)) & 7):
+ *     for lanes that agree in the bin, the copies, the two cell columns a group straddles and the four groups'
+ *     cell rows land on 32 different bank pairs.
  */
+constexpr int DESC_COPIES = 4;
+constexpr int DESC_MAXROWS = 128; /* patch rows handled by the span path */
+#ifndef DESC_GROUPS
+#define DESC_GROUPS 4 /* lane groups, each on its own 1 / DESC_GROUPS of the sample list */
+#endif
+constexpr int DESC_GL = 64 / DESC_GROUPS; /* lanes per group */
+
 __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
                                                        const float* __restrict__ arena, SiftConsts sc,
-                                                       const Counters* __restrict__ ct, const Ext* __restrict__ ext,
+                                                       Counters* __restrict__ ct, const Ext* __restrict__ ext,
                                                        const int* __restrict__ map, const float2* __restrict__ rot,
                                                        float* __restrict__ desc, int desc_cap)
 {
-    /* DCOPY private copies of the histogram per wave: neighbouring lanes sample neighbouring
-     * pixels, which mostly fall into the same cell and orientation bin; spreading them over
-     * copies by lane cuts the same-address serialisation of the LDS atomics */
-    constexpr int    DCOPY = 2;
-    constexpr int    MAXROWS = 256; /* patch rows handled by the span path */
-    __shared__ fix64 s_hist[KP_NW][DCOPY][128];
-    __shared__ int   s_start[KP_NW][MAXROWS + 1]; /* flat index of the first sample of each patch row */
-    __shared__ short s_lo[KP_NW][MAXROWS];        /* first column of each patch row's span */
-    const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    fix64*           hist = s_hist[wave][lane & (DCOPY - 1)];
-    fix64*           hall = s_hist[wave][0];
-    int*             rstart = s_start[wave];
-    short*           rlo = s_lo[wave];
-    const int        total = min(ct->ori_total, desc_cap);
-    const int        L = pdp->L;
+    __shared__ __attribute__((aligned(1024))) fix64 s_hist[KP_NW][DESC_COPIES * 128];
+    /* per patch row: flat index of its first sample (20 bits) | first column of its span relative to xmin (12 bits) */
+    __shared__ unsigned int s_row[KP_NW][DESC_MAXROWS + 1];
+    const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int     grp = lane / DESC_GL, sub = lane % DESC_GL, cpy = lane & (DESC_COPIES - 1);
+    fix64*        hall = s_hist[wave];
+    char*         hbase = (char*)(hall + cpy * 128);
+    unsigned int* rinfo = s_row[wave];
+    const int     total = min(ct->ori_total, desc_cap);
+    const int     L = pdp->L;
 
-    for (int d = blockIdx.x * KP_NW + wave; d < total; d += gridDim.x * KP_NW) {
+    for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
+        const int d = sl.index();
+        if (d >= total) continue;
         const Ext*     e = ext + map[d];
         const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
         const OctDesc* od = &pdp->o[e->octave];
         /* everything about the descriptor is wave-uniform: say so, and the plane base, the pitch and the bounds live in
-         * scalar registers (the taps become scalar-base + 32-bit-offset loads): 574 -> 539 us */
+         * scalar registers (the taps become scalar-base + 32-bit-offset loads) */
         const int      width = uniform(od->w), height = uniform(od->h), pitch = uniform(od->pitch);
         const int      lvl = min(max(e->lpos, 0), L - 1);
         const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
 
 #pragma unroll
-        for (int k = 0; k < 2 * DCOPY; k++) hall[lane + 64 * k] = 0ull;
+        for (int k = 0; k < 2 * DESC_COPIES; k++) hall[lane + 64 * k] = 0ull;
 
         const float SBP = fabsf(DESC_MAGNIFY * sigma);
         /* Each cell word packs two 32-bit fixed-point sums: low = share of orientation bin b, high =
@@ -564,11 +658,14 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
          * window weights) and a cell sees at most (2.83*SBP+1)^2 pixels. */
         const float cell_px = (2.83f * SBP + 1.0f) * (2.83f * SBP + 1.0f);
         const int   fbits = min(max(31 - (int)ceilf(log2f(361.0f * cell_px)), 2), 20);
-        const float fscale = scalbnf(1.0f, fbits);
+        const float fscale = uniformf(scalbnf(1.0f, fbits));
         if (SBP != 0.0f) {
             float sin_t, cos_t;
             cos_t = uniformf(rot[d].x);
             sin_t = uniformf(rot[d].y);
+            /* the orientation this descriptor belongs to, in units of one descriptor bin (pi / 4) */
+            const int   ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
+            const float ang_bins = uniformf(e->orientation[ko] * (4.0f / F_PI));
             const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
             const float crsbp = cos_t / SBP, srsbp = sin_t / SBP;
             const float bsz = fabsf(csbp) + fabsf(ssbp);
@@ -580,6 +677,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
             const int   ymax = min(height - 2, (int)floorf(y + ext_r) + 1);
             const int   wx = xmax - xmin + 1;
             const int   hy = ymax - ymin + 1;
+            const bool  spans = (hy <= DESC_MAXROWS && wx < 4096);
 
             /* Row spans.  The samples that count lie in the square |u|,|v| < 2.5 (cell units, rotated
              * by ang), which fills only 1/(|cos|+|sin|)^2 = 50..100 % of its bounding box.  Per patch
@@ -588,7 +686,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
              * that passes the exact test below.  Intervals are widened by a pixel: they only have
              * to be a superset. */
             int T = 0;
-            if (wx > 0 && hy > 0 && hy <= MAXROWS) {
+            if (wx > 0 && hy > 0 && spans) {
                 const float inv_c = (fabsf(crsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(crsbp) : 0.0f;
                 const float inv_s = (fabsf(srsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(srsbp) : 0.0f;
                 int         carry = 0;
@@ -617,6 +715,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                         jlo = max(xmin, (int)floorf(x + lo - 0.01f));
                         const int jhi = min(xmax, (int)ceilf(x + hi + 0.01f));
                         len = ok ? max(jhi - jlo + 1, 0) : 0;
+                        if (len == 0) jlo = xmin;
                     }
                     int incl = len;
 #pragma unroll
@@ -624,31 +723,53 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                         const int v = __shfl_up(incl, s);
                         if (lane >= s) incl += v;
                     }
-                    if (r < hy) {
-                        rstart[r] = carry + incl - len;
-                        rlo[r] = (short)jlo;
-                    }
+                    if (r < hy) rinfo[r] = (unsigned int)(carry + incl - len) | ((unsigned int)(jlo - xmin) << 20);
                     carry += __shfl(incl, 63);
                 }
                 T = carry;
-                if (lane == 0) rstart[hy] = T;
+                if (lane == 0) rinfo[hy] = (unsigned int)T;
             }
             wave_lds_sync();
 
-            const bool  spans = (hy <= MAXROWS);
             const int   loops = spans ? T : ((wx > 0 && hy > 0) ? wx * hy : 0);
             const float inv_wx = 1.0f / (float)max(wx, 1);
-            int         row = 0;
+            /* every lane group takes its own part of the list */
+            const int   quarter = (loops + DESC_GROUPS - 1) / DESC_GROUPS;
+            const int   ibeg = grp * quarter, iend = min(ibeg + quarter, loops);
+            const int   iters = (quarter + DESC_GL - 1) / DESC_GL;
+            int          row = 0;
+            unsigned int cur = 0;
+            if (spans && loops > 0) {
+                /* the row that holds this lane's first sample: largest r with start(r) <= i0 (empty rows share the
+                 * start of their successor, so that row is not empty) */
+                const int i0 = min(ibeg + sub, loops - 1);
+                int       lo = 0, hi = hy - 1;
+#pragma unroll
+                for (int it = 0; it < 7; it++) { /* DESC_MAXROWS = 2^7 */
+                    const int mid = (lo + hi + 1) >> 1;
+                    if ((int)(rinfo[mid] & 0xfffffu) <= i0)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                row = lo;
+                cur = rinfo[row];
+            }
 
-            /* Two-stage software pipeline: the coordinates of sample i+64 are computed and its four
-             * gradient taps requested while sample i is being binned, so the L2 round trip of the taps
-             * (41 % of the wave cycles were spent waiting on it) overlaps the arithmetic.  The loads are
-             * unconditional (in-bounds for every span / box position) to keep the vmcnt waits counted. */
+            /* Two-stage software pipeline: the coordinates of the lane's next sample are computed and its four
+             * gradient taps requested while the current one is being binned, so the L2 round trip of the taps
+             * overlaps the arithmetic.  The loads are unconditional (in-bounds for every span / box position) to
+             * keep the vmcnt waits counted. */
             auto coord = [&](int i, int& off, float& u, float& v) {
                 int ii, jj;
                 if (spans) {
-                    while (i >= rstart[row + 1]) row++;
-                    jj = rlo[row] + (i - rstart[row]);
+                    unsigned int nxt = rinfo[row + 1];
+                    while (i >= (int)(nxt & 0xfffffu)) {
+                        row++;
+                        cur = nxt;
+                        nxt = rinfo[row + 1];
+                    }
+                    jj = xmin + (int)(cur >> 20) + (i - (int)(cur & 0xfffffu));
                     ii = ymin + row;
                 } else { /* enormous patches: plain bounding-box scan */
                     const int rr = (int)(((float)i + 0.5f) * inv_wx);
@@ -662,28 +783,15 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                 v = fmaf(crsbp, dy, -srsbp * dx);
                 off = __mul24(ii, pitch) + jj;
             };
-            int   off_n = 0;
-            float u_n = 3.0f, v_n = 3.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
-            const Taps taps(layer, pitch);
-            if (loops > 0) {
-                coord(min(lane, loops - 1), off_n, u_n, v_n);
-                taps.load(off_n, g0, g1, g2, g3);
-            }
-            for (int i = lane; i < loops; i += 64) {
-                const float u = u_n, v = v_n;
-                const float gx = g0 - g1, gy = g2 - g3;
-                {
-                    coord(min(i + 64, loops - 1), off_n, u_n, v_n);
-                    taps.load(off_n, g0, g1, g2, g3);
-                }
-                if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
+            /* one sample: gradient (gx, gy) at cell-unit position (u, v) -> up to four 64-bit LDS atomics */
+            auto bin = [&](float u, float v, float gx, float gy, bool live) {
+                if (live && fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
                     const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
                     /* exp(-(u^2+v^2)/8) = 2^(-(u^2+v^2) * log2(e)/8) */
                     const float  ww = __builtin_amdgcn_exp2f(-0.18033688011112042f * (u * u + v * v));
-                    /* gradient angle relative to the keypoint orientation, in units of one bin:
-                     * rotate the gradient by -ang, then atan2 (same as atan2(gy,gx) - ang wrapped) */
-                    float tth = atan2_bins(fmaf(cos_t, gy, -sin_t * gx), fmaf(cos_t, gx, sin_t * gy));
-                    tth += (tth < 0.0f) ? 8.0f : 0.0f;
+                    /* gradient angle relative to the keypoint orientation in units of one bin; any multiple of 8 may be
+                     * missing: floor / fraction / (& 7) below do not care */
+                    const float tth = atan2_bins(gy, gx) - ang_bins;
                     const float ffo = floorf(tth);
                     const float do0 = tth - ffo;
                     const int   b0 = (int)ffo & 7;
@@ -700,35 +808,63 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     const float wx1 = (cx0 <= 2) ? fx : 0.0f;
                     const float wy0 = (cy0 >= 0) ? (1.0f - fy) * wm : 0.0f;
                     const float wy1 = (cy0 <= 2) ? fy * wm : 0.0f;
-                    const int   ix0 = max(cx0, 0), ix1 = min(cx0 + 1, 3);
-                    const int   iy0 = max(cy0, 0), iy1 = min(cy0 + 1, 3);
                     const float w1 = do0, w0 = 1.0f - do0;
-#define PS_CELL(IY, IX, WGT)                                                              \
+                    /* byte addresses of the four words (a word is only touched when its weight is positive, and then
+                     * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped) */
+                    const int k0 = (cx0 + cy0) & 3;
+                    const int s0 = ((b0 + cpy + ((cx0 & 1) << 2)) & 7) << 3;
+                    char*     e0 = hbase + (cy0 << 8) + s0;
+                    char*     e1 = hbase + (cy0 << 8) + (s0 ^ 32);
+#define PS_CELL(ADDR, WGT)                                                                \
     {                                                                                     \
         const float wgt = (WGT);                                                          \
         if (wgt > 0.0f) {                                                                 \
             const unsigned int lo = (unsigned int)fmaf(w0, wgt, 0.5f);                    \
             const unsigned int hi = (unsigned int)fmaf(w1, wgt, 0.5f);                    \
-            atomicAdd(&hist[((((IY) << 2) + (IX)) << 3) + b0], ((fix64)hi << 32) | lo);  \
+            atomicAdd((fix64*)(ADDR), ((fix64)hi << 32) | lo);                           \
         }                                                                                 \
     }
-                    PS_CELL(iy0, ix0, wy0 * wx0)
-                    PS_CELL(iy0, ix1, wy0 * wx1)
-                    PS_CELL(iy1, ix0, wy1 * wx0)
-                    PS_CELL(iy1, ix1, wy1 * wx1)
+                    PS_CELL(e0 + (k0 << 6), wy0 * wx0)
+                    PS_CELL(e1 + (((k0 + 1) & 3) << 6), wy0 * wx1)
+                    PS_CELL(e0 + (((k0 + 1) & 3) << 6) + 256, wy1 * wx0)
+                    PS_CELL(e1 + (((k0 + 2) & 3) << 6) + 256, wy1 * wx1)
 #undef PS_CELL
                 }
+            };
+            /* two register sets take turns as "being binned" and "in flight" (the loop is unrolled by two so that no
+             * value has to be copied from one role to the other) */
+            int   off_a = 0, off_b = 0;
+            float u_a = 3.0f, v_a = 3.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            float u_b = 3.0f, v_b = 3.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+            const Taps taps(layer, pitch);
+            if (loops > 0) {
+                coord(min(ibeg + sub, loops - 1), off_a, u_a, v_a);
+                taps.load(off_a, a0, a1, a2, a3);
+            }
+            for (int t = 0, i = ibeg + sub; t < iters; t += 2, i += 2 * DESC_GL) {
+                coord(min(i + DESC_GL, loops - 1), off_b, u_b, v_b);
+                taps.load(off_b, b0, b1, b2, b3);
+                bin(u_a, v_a, a0 - a1, a2 - a3, i < iend);
+                coord(min(i + 2 * DESC_GL, loops - 1), off_a, u_a, v_a);
+                taps.load(off_a, a0, a1, a2, a3);
+                bin(u_b, v_b, b0 - b1, b2 - b3, i + DESC_GL < iend);
             }
         }
         wave_lds_sync();
 
-        /* bin b of a cell = low half of word b + high half of word b-1 (mod 8), over the copies */
-        fix64     a0 = 0ull, a1 = 0ull;
-        const int prevw = (lane & ~7) | ((lane + 7) & 7);
+        /* bin b of cell (iy, ix) = low half of that cell's word for b + high half of its word for b-1 (mod 8),
+         * summed over the copies; word positions as in the header comment */
+        fix64 a0 = 0ull, a1 = 0ull;
+        {
+            const int b = lane & 7, ix = (lane >> 3) & 3, iyl = lane >> 5; /* element lane: cell row iyl, lane+64: iyl+2 */
 #pragma unroll
-        for (int k = 0; k < DCOPY; k++) {
-            a0 += (hall[k * 128 + lane] & 0xffffffffull) + (hall[k * 128 + prevw] >> 32);
-            a1 += (hall[k * 128 + lane + 64] & 0xffffffffull) + (hall[k * 128 + prevw + 64] >> 32);
+            for (int k = 0; k < DESC_COPIES; k++) {
+                const int sl = (b + k + ((ix & 1) << 2)) & 7, sh = (b + 7 + k + ((ix & 1) << 2)) & 7;
+                const int c0 = k * 128 + iyl * 32 + ((ix + iyl) & 3) * 8;
+                const int c1 = k * 128 + (iyl + 2) * 32 + ((ix + iyl + 2) & 3) * 8;
+                a0 += (hall[c0 + sl] & 0xffffffffull) + (hall[c0 + sh] >> 32);
+                a1 += (hall[c1 + sl] & 0xffffffffull) + (hall[c1 + sh] >> 32);
+            }
         }
         const float inv_scale = scalbnf(1.0f, -fbits);
         float       v0 = (float)a0 * inv_scale, v1 = (float)a1 * inv_scale;
@@ -775,7 +911,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
  */
 __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restrict__ pdp,
                                                          const float* __restrict__ arena, SiftConsts sc,
-                                                         const Counters* __restrict__ ct,
+                                                         Counters* __restrict__ ct,
                                                          const Ext* __restrict__ ext, const int* __restrict__ map,
                                                          const float2* __restrict__ rot, float* __restrict__ desc,
                                                          int desc_cap)
@@ -788,7 +924,9 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
     const float      M_4RPI = 4.0f / F_PI;
     const int        xd = lane & 15, ysub = lane >> 4;
 
-    for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
+    for (XcdSlice sl = xcd_slice<4>(); sl.more(total); sl.s += sl.step) {
+        const int d = sl.index();
+        if (d >= total) continue;
         const Ext*     e = ext + map[d];
         const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
         const int      ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
@@ -924,7 +1062,7 @@ __device__ __forceinline__ float tex_linear(const float* pl, int w, int h, int p
 template <bool ILOOP>
 __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __restrict__ pdp,
                                                            const float* __restrict__ arena, SiftConsts sc,
-                                                           const Counters* __restrict__ ct,
+                                                           Counters* __restrict__ ct,
                                                            const Ext* __restrict__ ext, const int* __restrict__ map,
                                                            const float2* __restrict__ rot, float* __restrict__ desc,
                                                            int desc_cap)
@@ -942,7 +1080,9 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
     const float      stepbase = -2.5f + 1.0f / 16.0f;
     const float      fscale = (float)(1 << FBITS);
 
-    for (int d = blockIdx.x * 4 + wave; d < total; d += gridDim.x * 4) {
+    for (XcdSlice sl = xcd_slice<4>(); sl.more(total); sl.s += sl.step) {
+        const int d = sl.index();
+        if (d >= total) continue;
         const Ext*     e = ext + map[d];
         const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
         const OctDesc* od = &pdp->o[e->octave];
@@ -1087,24 +1227,25 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
 
 }  // namespace
 
-hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
-                              const InitExt* iext, Ext* ext, int blocks, hipStream_t s)
+hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftConsts& sc, Counters* ct,
+                              const InitExt* iext, float* ohist, int hist_cap, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orientation, dim3(blocks * 4 / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, iext, ext);
+    hipLaunchKernelGGL(k_orientation, dim3(blocks / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, iext, ohist, hist_cap);
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, Ext* ext, int* partial, int n_chunks,
-                       int* map, float2* rot, popsift_hip_feature* feats, int desc_cap, hipStream_t s)
+hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
+                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot,
+                       popsift_hip_feature* feats, int desc_cap, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial);
+    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
     hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, feats, desc_cap);
     return hipGetLastError();
 }
 
 int scan_chunk() { return SCAN_CHUNK; }
 
-hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, const Counters* ct,
+hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, Counters* ct,
                               const Ext* ext, const int* map, const float2* rot, float* desc, int desc_cap, int blocks,
                               hipStream_t s)
 {
@@ -1112,13 +1253,13 @@ hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftC
      * cell by cell (each point up to four times); the two differ only in summation order (6e-7 relative in the
      * oracle), so both run the one-evaluation-per-point kernel */
     if (sc.desc_mode == POPSIFT_HIP_DESC_NOTILE || sc.desc_mode == POPSIFT_HIP_DESC_IGRID)
-        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_ILOOP)
-        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
-        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else
-        hipLaunchKernelGGL(k_descriptor, dim3(blocks * 4 / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor, dim3(blocks / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     return hipGetLastError();
 }
 

@@ -20,8 +20,6 @@
  */
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "sift_types.h"
 #include "kernels.h"
 
@@ -119,11 +117,6 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                 const int    gy = clampi(ty0 + r - HALO, 0, h - 1);
                 const int    gx0 = tx0 + 4 * c4 - HP;
                 const float* row = src + (size_t)gy * pitch;
-#ifdef BLUR_NO_LOAD /* tools/blur_phase_probe.sh: timing probe, results are wrong */
-                if (true) {
-                    v[k] = v4f{(float)gx0, (float)gy, 1.0f, 2.0f};
-                } else
-#endif
                 if (gx0 >= 0 && gx0 + 3 < w) {
                     v[k] = *reinterpret_cast<const v4f*>(row + gx0);
                 } else {
@@ -297,14 +290,9 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
     for (int g = 0; g < GROUPS; g++) {
         const int rg = (tid >> 5) + g * (NT / 32);
 #pragma unroll
-#ifdef BLUR_NO_H /* tools/blur_phase_probe.sh: timing probe, results are wrong */
-        for (int j = 0; j < 4; j++) old[g][j] = *reinterpret_cast<const v4f*>(&s_t[(HALO + 4 * rg + j) * SW + HP + lx]);
-    }
-#else
         for (int j = 0; j < 4; j++) old[g][j] = hrow(HALO + 4 * rg + j);
     }
     for (int hh = tid >> 5; hh < 2 * HALO; hh += NT / 32) (void)hrow(hh < HALO ? hh : TH + hh);
-#endif
     __syncthreads();
 
     /* ---- phase 3: vertical pass, 4 columns x 4 rows per lane, + DoG ------ */
@@ -336,24 +324,16 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
                     alo = __builtin_elementwise_fma(win[cpos].lo, g0, alo);
                     ahi = __builtin_elementwise_fma(win[cpos].hi, g0, ahi);
                 }
-#ifdef BLUR_NO_V /* tools/blur_phase_probe.sh: timing probe, results are wrong */
-                const v4f acc = win[cpos] + win[cpos + HALO] + win[cpos - HALO];
-#else
                 const v4f acc = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3);
-#endif
                 const int gy = ty0 + r0 + o;
                 if (gx < w && gy < h) {
                     /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */
                     /* the Gaussian plane is the next level's input (keep it cached); the DoG plane is not touched again
                      * before the detection kernel: a non-temporal store keeps it from evicting the plane
                      * (measured: level launches -4 %, detection -7 %; non-temporal for both: levels +20 %) */
-#ifdef BLUR_NO_STORE /* tools/blur_phase_probe.sh: timing probe, results are wrong */
-                    if (acc.x == 1.2345e30f) a.dst[0] = acc.y + old[g][o].x;
-#else
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
                     if (MODE == 0 && a.dog)
                         __builtin_nontemporal_store(acc - old[g][o], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
-#endif
                     /* the next octave's level 0 takes pixel (2x, 2y): its width is ceil(w / 2), so 2x <= w - 1 always
                      * and the reference's min(2x, w - 1) never clamps.  gx is a multiple of 4. */
                     if (MODE == 0 && a.next0 && (gy & 1) == 0) {
@@ -412,10 +392,7 @@ int blur_tile_w() { return TW; }
  * still yields a couple of tiles per CU (measured: +3 % throughput at 1080p) */
 int blur_tile_h(int w, int h)
 {
-    static const long min_tiles = []() {
-        const char* e = getenv("POPSIFT_HIP_TILE64_MIN"); /* tuning knob */
-        return e ? atol(e) : 512L;
-    }();
+    constexpr long min_tiles = 512;
     const long tiles64 = (long)((w + TW - 1) / TW) * ((h + 63) / 64);
     return tiles64 >= min_tiles ? 64 : 32;
 }
@@ -424,10 +401,7 @@ hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStr
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    static const int nt64 = []() {
-        const char* e = getenv("POPSIFT_HIP_BLUR_NT64"); /* tuning knob: lanes per 64-row tile */
-        return (e && atoi(e) == 256) ? 256 : 512;
-    }();
+    constexpr int nt64 = 512;
     /* 512 lanes per 64-row tile halve the serial work per wave at the same LDS footprint (measured
      * -12 % per launch); the 27-tap instance needs ~150 VGPRs for its vertical window and is better
      * off with 256 lanes */

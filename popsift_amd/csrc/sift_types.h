@@ -76,10 +76,16 @@ struct Counters {
     int ext_total;
     int ori_total;
     int pad[2]; /* [0] unused, [1] strips left to the slow detection pass */
-    /* The detection kernel appends candidates to DET_SUBQ sub-queues (workgroup index mod DET_SUBQ), each with
-     * its own counter and its own slice of the candidate buffer: a returning atomicAdd on ONE address saturates
-     * near 90/us on MI355X, which cost the kernel 29 of its 106 us (one flush per strip, 5456 strips). */
-    int qcnt[64];
+    /* The detection kernel appends candidates to DET_SUBQ sub-queues, each with its own counter and its own slice of
+     * the candidate buffer: a returning atomicAdd on ONE address saturates near 90/us on MI355X, which cost the kernel
+     * 29 of its 106 us (one flush per strip, 5456 strips).  A sub-queue is a REGION of the image (an 8 x 8 grid over
+     * every octave): refinement takes the sub-queues one after the other and appends a batch of survivors at a time,
+     * so the extrema lists -- and with them the work of the orientation and descriptor kernels -- come out grouped by
+     * region without a sorting pass.  Every counter sits on a cache line of its own. */
+    struct {
+        int n;
+        int pad[31];
+    } qcnt[64];
 };
 #define DET_SUBQ 64
 

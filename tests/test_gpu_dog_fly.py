@@ -1,6 +1,6 @@
-"""POPSIFT_HIP_DOG_FLY=1 (DoG planes not stored; detection / refinement subtract the Gaussian planes they
-load) must give bit-identical planes, extrema, features and descriptors to the stored-DoG path.  The switch
-is read once per process, so each mode runs in its own child process on the same seeded image."""
+"""params.store_dog = 0 (the default: DoG planes not stored; detection / refinement subtract the Gaussian planes
+they load) must give bit-identical planes, extrema, features and descriptors to the stored-DoG path
+(store_dog = 1, what the reference does).  Each mode runs in its own child process on the same seeded images."""
 import os
 import subprocess
 import sys
@@ -18,7 +18,7 @@ from popsift_amd.synth import synth
 out = {}
 for tag, spec, kw in (("a", (5, 640, 480), {}), ("b", (9, 333, 251), {"sift_mode": 1, "octaves": 3}),
                       ("c", (11, 400, 300), {"sift_mode": 2})):
-    ctx = hip.Context(hip.default_params(**kw))
+    ctx = hip.Context(hip.default_params(store_dog=int(sys.argv[3]), **kw))
     ctx.submit(synth(*spec))
     feats, desc = ctx.fetch()
     # canonical order (the device's compaction order is arbitrary): octave, y, x, sigma
@@ -38,15 +38,14 @@ np.savez(sys.argv[2], **out)
 
 
 def _run(mode, path):
-    env = dict(os.environ, POPSIFT_HIP_DOG_FLY=str(mode))
-    subprocess.run([sys.executable, "-c", CHILD, ROOT, path], env=env, check=True, timeout=600)
+    subprocess.run([sys.executable, "-c", CHILD, ROOT, path, str(mode)], check=True, timeout=600)
     return np.load(path)
 
 
 @pytest.mark.gpu
 def test_dog_on_the_fly_is_bit_identical(tmp_path):
-    stored = _run(0, str(tmp_path / "stored.npz"))
-    fly = _run(1, str(tmp_path / "fly.npz"))
+    stored = _run(1, str(tmp_path / "stored.npz"))
+    fly = _run(0, str(tmp_path / "fly.npz"))
     assert sorted(stored.files) == sorted(fly.files)
     for k in stored.files:
         assert stored[k].shape == fly[k].shape, k

@@ -220,14 +220,15 @@ def test_max_extrema_cap_and_buffer_growth(oracle_mod, gpu_hip):
     assert all(k in allk for k in zip(capped["octave"].tolist(), capped["xpos"].tolist(), capped["ypos"].tolist()))
 
 
-def test_candidate_buffer_regrows(gpu_hip, monkeypatch):
-    """More candidates than a sub-queue slice holds: finish() grows the buffer and redoes the keypoint stages."""
+def test_candidate_and_histogram_buffers_regrow(gpu_hip):
+    """More candidates than a sub-queue slice holds / more extrema than the orientation-histogram buffer holds:
+    finish() grows the buffers and redoes the keypoint stages."""
     img = synth(44, 320, 240)
     want = sorted_features(*gpu_hip.Context().submit(img).fetch())
-    monkeypatch.setenv("POPSIFT_HIP_CAND_CAP", "256")            # 4 entries per sub-queue
     ctx = gpu_hip.Context()
+    ctx.debug_set(gpu_hip.DEBUG_CAND_CAP, 256)                   # 4 entries per sub-queue
+    ctx.debug_set(gpu_hip.DEBUG_OHIST_CAP, 100)                  # 100 extrema
     got = sorted_features(*ctx.submit(img).fetch())
-    monkeypatch.delenv("POPSIFT_HIP_CAND_CAP")
     assert len(want[0]) > 1000
     assert np.array_equal(got[0]["xpos"], want[0]["xpos"]) and np.array_equal(bits(got[1]), bits(want[1]))
     got2 = sorted_features(*ctx.submit(img).fetch())             # grown buffer is kept
@@ -268,15 +269,46 @@ def test_stage_isolation_with_uploaded_planes(oracle_mod, gpu_hip):
     for those planes (checks the stages independently of the pyramid kernel)."""
     img = synth(60, 160, 120)
     orc = oracle_mod.Oracle(threads=4).run(img)
-    ctx = gpu_hip.Context()
-    ctx.submit(np.zeros_like(img)).wait()
-    for o in range(orc.num_octaves):
-        for l in range(6):
-            ctx.upload_plane(o, 0, l, orc.plane(o, 0, l))
-        for l in range(5):
-            ctx.upload_plane(o, 1, l, orc.plane(o, 1, l))
-    ctx.rerun_keypoint_stages()
-    assert_keypoints_match(orc, ctx)
+    for store_dog in (0, 1):
+        ctx = gpu_hip.Context(gpu_hip.default_params(store_dog=store_dog))
+        ctx.submit(np.zeros_like(img)).wait()
+        for o in range(orc.num_octaves):
+            for l in range(6):
+                ctx.upload_plane(o, 0, l, orc.plane(o, 0, l))
+            for l in range(5):
+                if store_dog:
+                    ctx.upload_plane(o, 1, l, orc.plane(o, 1, l))
+                else:                                  # DoG values are formed from the Gaussian planes
+                    with pytest.raises(gpu_hip.PopsiftHipError) as e:
+                        ctx.upload_plane(o, 1, l, orc.plane(o, 1, l))
+                    assert e.value.status == gpu_hip.ERR_STATE
+        ctx.rerun_keypoint_stages()
+        assert_keypoints_match(orc, ctx)
+
+
+def test_failed_allocation_leaves_the_context_usable(gpu_hip):
+    """A failed (re)allocation while sizing for a new image is a recoverable POPSIFT_HIP_ERR_OOM: the context must
+    not keep the geometry of buffers it has freed (resubmitting the OLD size used to launch on a null arena)."""
+    a, b = synth(70, 200, 150), synth(71, 320, 240)
+    want_a = sorted_features(*gpu_hip.Context().submit(a).fetch())
+    want_b = sorted_features(*gpu_hip.Context().submit(b).fetch())
+    for nth in (1, 2, 3, 5):
+        ctx = gpu_hip.Context()
+        got = sorted_features(*ctx.submit(a).fetch())
+        assert np.array_equal(bits(got[1]), bits(want_a[1]))
+        ctx.debug_set(gpu_hip.DEBUG_FAIL_ALLOC, nth)   # the bigger image makes the arena (1st allocation) grow
+        try:
+            ctx.submit(b)
+            failed = False
+        except gpu_hip.PopsiftHipError as e:
+            assert e.status == gpu_hip.ERR_OOM
+            failed = True
+        ctx.debug_set(gpu_hip.DEBUG_FAIL_ALLOC, 0)
+        assert failed or nth > 1
+        got = sorted_features(*ctx.submit(a).fetch())   # the old size again: must re-plan, not reuse freed buffers
+        assert np.array_equal(got[0]["xpos"], want_a[0]["xpos"]) and np.array_equal(bits(got[1]), bits(want_a[1]))
+        got = sorted_features(*ctx.submit(b).fetch())
+        assert np.array_equal(got[0]["xpos"], want_b[0]["xpos"]) and np.array_equal(bits(got[1]), bits(want_b[1]))
 
 
 def test_call_sequence_errors(gpu_hip):
@@ -298,16 +330,15 @@ def test_call_sequence_errors(gpu_hip):
     assert rc == gpu_hip.ERR_INVALID          # pitch < width
 
 
-def test_detection_slow_pass_gives_the_same_extrema(gpu_hip, monkeypatch):
+def test_detection_slow_pass_gives_the_same_extrema(gpu_hip):
     """Strips with more candidates than the per-wave queue holds are re-done by the slow
     instantiation of the detection kernel; shrinking the queue to 4 entries sends almost every
     strip there, and the result must not change."""
     img = synth(81, 400, 300)
     ref = gpu_hip.Context().submit(img)
     e0 = ref.extrema()
-    monkeypatch.setenv("POPSIFT_HIP_DET_QCAP", "4")
     ctx = gpu_hip.Context()
+    ctx.debug_set(gpu_hip.DEBUG_DET_QCAP, 4)
     e1 = ctx.submit(img).extrema()
-    monkeypatch.delenv("POPSIFT_HIP_DET_QCAP")
     key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
     assert len(e0) > 1000 and key(e0) == key(e1)

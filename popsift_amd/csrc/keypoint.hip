@@ -266,10 +266,11 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         if (g >= total) continue;
         int o = 0;
         while (o + 1 < n_oct && g >= ps[o + 1]) o++;
-        const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - ps[o])];
+        o = uniform(o); /* the octave record and the list entry are then fetched through the scalar cache */
+        const InitExt  ie = iext[(size_t)o * sc.max_extrema + (g - uniform(ps[o]))];
         const OctDesc* od = &pdp->o[o];
         const int      w = uniform(od->w), h = uniform(od->h), pitch = uniform(od->pitch);
-        const int      lvl = min(max(ie.lpos, 0), L - 1);
+        const int      lvl = uniform(min(max(ie.lpos, 0), L - 1));
         const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
 
         for (int k = lane; k < ORI_COPIES * PS_ORI_NBINS; k += 64) hall[k] = 0ull;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         auto coord = [&](int i, int& xx, int& yy) {
             const int row = (int)(((float)i + 0.5f) * inv_wx);
             yy = row + ymin;
-            xx = i - row * wx + xmin;
+            xx = i - __mul24(row, wx) + xmin;
         };
         int   xn = xmin, yn = ymin;
         float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
@@ -314,11 +315,15 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
             const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
             if (sq_dist <= sq_thres) {
                 const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
-                const float theta = atan2_acc(gdy, gdx);
                 const float weight = grad * __expf(sq_dist * factor);
                 /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the reference's quotient only when
-                 * the result is within an ulp of k + 0.5 */
-                int         bidx = (int)roundf((theta + F_PI) * ((float)PS_ORI_NBINS / F_PI2));
+                 * the result is within an ulp of k + 0.5.
+                 * The bin is a HARD decision, so the angle needs libm-grade accuracy -- but only when it lies next
+                 * to a bin edge: the cheap atan2 (error < 5e-7 rad = 3e-6 bins) decides every sample farther than
+                 * 1e-4 bins from an edge, identically to the accurate one, which the others (1 in 5000) then take. */
+                float       fb = (fast_atan2(gdy, gdx) + F_PI) * ((float)PS_ORI_NBINS / F_PI2);
+                if (fabsf(fb - floorf(fb) - 0.5f) < 1e-4f) fb = (atan2_acc(gdy, gdx) + F_PI) * ((float)PS_ORI_NBINS / F_PI2);
+                int         bidx = (int)roundf(fb);
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
                 if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));
             }
@@ -336,62 +341,108 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
 }
 
 /*
- * ori_par, second half (s_orientation.cu:142-240), one lane per extremum: six circular box-filter passes, parabolic
- * peak interpolation, the (at most four) best peaks within 80 % of the best -- BitonicSort::Warp32::sort64
- * (common/warp_bitonic_sort.h:35-78) becomes four in-register selection rounds, ties to the lower bin.
- * Everything is indexed statically (fully unrolled), so the 36 bins live in registers.
+ * ori_par, second half (s_orientation.cu:142-240), FOUR lanes per extremum, nine of the 36 bins each: six circular
+ * box-filter passes, parabolic peak interpolation, the (at most four) best peaks within 80 % of the best.  The lanes of
+ * a quad exchange their edge bins and their candidates with DPP quad permutes (register-to-register, no LDS);
+ * BitonicSort::Warp32::sort64 (common/warp_bitonic_sort.h:35-78) becomes four selection rounds, ties to the lower
+ * bin.  Everything is indexed statically, so the bins live in registers.  (One LANE per extremum -- 36 bins in
+ * registers, no exchange at all -- needs only 1200 waves for a 1080p image: 24 us at barely one wave per SIMD.)
+ * All four lanes of a quad must be active; all return the same result.
  */
-__device__ __forceinline__ int ori_peaks(const float* __restrict__ hsrc, float* angle_out)
+__device__ __forceinline__ float quad_from_prev(float v) /* lane j of a quad reads lane (j + 3) & 3 */
 {
-    constexpr int N = PS_ORI_NBINS;
-    float         h[N], t[N];
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float quad_from_next(float v) /* lane j reads lane (j + 1) & 3 */
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x39, 0xf, 0xf, false));
+}
+template <int CTRL> /* 0xB1: lane ^ 1, 0x4E: lane ^ 2 */
+__device__ __forceinline__ int quad_xchg(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+/* x / 3.0f, correctly rounded for normal x (Markstein: q = x * RN(1/3), one FMA residual, one FMA correction; checked
+ * against IEEE division for every float of six binades, tools/check_div3.py) instead of the ten-instruction division */
+__device__ __forceinline__ float div3(float x)
+{
+    const float r = 0.333333343267440796f; /* RN(1/3) */
+    const float q = x * r;
+    return fmaf(fmaf(-3.0f, q, x), r, q);
+}
+
+__device__ __forceinline__ int ori_peaks_quad(const float* __restrict__ hsrc, int j, bool have, float* angle_out)
+{
+    constexpr int N = PS_ORI_NBINS, M = N / 4; /* 9 bins per lane: 9j .. 9j+8 */
+    float         h[M], t[M];
 #pragma unroll
-    for (int q = 0; q < N / 4; q++) {
-        const float4 v = reinterpret_cast<const float4*>(hsrc)[q];
-        h[4 * q + 0] = v.x;
-        h[4 * q + 1] = v.y;
-        h[4 * q + 2] = v.z;
-        h[4 * q + 3] = v.w;
-    }
+    for (int b = 0; b < M; b++) h[b] = have ? hsrc[M * j + b] : 0.0f;
 #pragma unroll
     for (int pass = 0; pass < 3; pass++) {
+        {
+            const float lft = quad_from_prev(h[M - 1]), rgt = quad_from_next(h[0]);
 #pragma unroll
-        for (int b = 0; b < N; b++) t[b] = (h[b == 0 ? N - 1 : b - 1] + h[b] + h[b == N - 1 ? 0 : b + 1]) / 3.0f;
+            for (int b = 0; b < M; b++) t[b] = div3(((b == 0 ? lft : h[b - 1]) + h[b]) + (b == M - 1 ? rgt : h[b + 1]));
+        }
+        {
+            const float lft = quad_from_prev(t[M - 1]), rgt = quad_from_next(t[0]);
 #pragma unroll
-        for (int b = 0; b < N; b++) h[b] = (t[b == 0 ? N - 1 : b - 1] + t[b] + t[b == N - 1 ? 0 : b + 1]) / 3.0f;
+            for (int b = 0; b < M; b++) h[b] = div3(((b == 0 ? lft : t[b - 1]) + t[b]) + (b == M - 1 ? rgt : t[b + 1]));
+        }
     }
-    float refined[N], yval[N];
+    float refined[M], yval[M];
+    {
+        const float lft = quad_from_prev(h[M - 1]), rgt = quad_from_next(h[0]);
 #pragma unroll
-    for (int b = 0; b < N; b++) {
-        const int   prev = b == 0 ? N - 1 : b - 1;
-        const float hp = h[prev], hv = h[b], hn = h[b == N - 1 ? 0 : b + 1];
-        bool        predicate = hv > fmaxf(hp, hn);
-        const float num = predicate ? 3.0f * hp - 4.0f * hv + 1.0f * hn : 0.0f;
-        const float denB = predicate ? 2.0f * (hp - 2.0f * hv + hn) : 1.0f;
-        const float newbin = num / denB;
-        predicate = (predicate && newbin >= 0.0f && newbin <= 2.0f);
-        refined[b] = predicate ? prev + newbin : -1.0f;
-        yval[b] = predicate ? -(num * num) / (4.0f * denB) + hp : -INFINITY;
+        for (int b = 0; b < M; b++) {
+            const int   bin = M * j + b;
+            const int   prev = (bin == 0) ? N - 1 : bin - 1;
+            const float hp = (b == 0) ? lft : h[b - 1], hv = h[b], hn = (b == M - 1) ? rgt : h[b + 1];
+            bool        predicate = hv > fmaxf(hp, hn);
+            const float num = predicate ? 3.0f * hp - 4.0f * hv + 1.0f * hn : 0.0f;
+            const float denB = predicate ? 2.0f * (hp - 2.0f * hv + hn) : 1.0f;
+            const float newbin = num / denB;
+            predicate = (predicate && newbin >= 0.0f && newbin <= 2.0f);
+            refined[b] = predicate ? prev + newbin : -1.0f;
+            yval[b] = predicate ? -(num * num) / (4.0f * denB) + hp : -INFINITY;
+        }
     }
-    unsigned long long used = 0ull;
-    float              best0 = 0.0f;
-    int                angles = 0;
+    unsigned int used = 0u; /* of this lane's nine bins */
+    float        best0 = 0.0f;
+    int          angles = 0;
 #pragma unroll
     for (int k = 0; k < POPSIFT_HIP_ORI_MAX; k++) {
-        /* first unused bin, then any later unused bin with a strictly larger value */
+        /* best unused bin of this lane: largest value, lowest bin on ties (every lane has unused bins: 9 > 4) */
         float bv = 0.0f, br = -1.0f;
         int   bi = -1;
 #pragma unroll
-        for (int b = 0; b < N; b++) {
-            const bool free_b = !((used >> b) & 1ull);
-            const bool take = free_b && (bi < 0 || yval[b] > bv);
+        for (int b = 0; b < M; b++) {
+            const bool take = !((used >> b) & 1u) && (bi < 0 || yval[b] > bv);
             bv = take ? yval[b] : bv;
             br = take ? refined[b] : br;
-            bi = take ? b : bi;
+            bi = take ? M * j + b : bi;
         }
-        used |= 1ull << bi;
+        /* ... of the quad */
+        {
+            const float ov = __int_as_float(quad_xchg<0xB1>(__float_as_int(bv))), orf = __int_as_float(quad_xchg<0xB1>(__float_as_int(br)));
+            const int   oi = quad_xchg<0xB1>(bi);
+            const bool  take = ov > bv || (ov == bv && oi < bi);
+            bv = take ? ov : bv;
+            br = take ? orf : br;
+            bi = take ? oi : bi;
+        }
+        {
+            const float ov = __int_as_float(quad_xchg<0x4E>(__float_as_int(bv))), orf = __int_as_float(quad_xchg<0x4E>(__float_as_int(br)));
+            const int   oi = quad_xchg<0x4E>(bi);
+            const bool  take = ov > bv || (ov == bv && oi < bi);
+            bv = take ? ov : bv;
+            br = take ? orf : br;
+            bi = take ? oi : bi;
+        }
+        const int mine = bi - M * j;
+        if (mine >= 0 && mine < M) used |= 1u << mine;
         if (k == 0) best0 = bv;
-        /* yval is visited in descending order, so the accepted ones are a prefix */
+        /* the candidates come in descending order, so the accepted ones are a prefix */
         if (bv >= 0.8f * best0) {
             float chosen_bin = br;
             if (chosen_bin >= N) chosen_bin -= N;
@@ -427,48 +478,45 @@ __device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConst
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                    const Counters* __restrict__ ct, const InitExt* __restrict__ iext,
-                                                    const float* __restrict__ ohist, int hist_cap,
-                                                    Ext* __restrict__ ext, int* __restrict__ partial)
+__global__ __launch_bounds__(1024) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+                                                     const Counters* __restrict__ ct, const InitExt* __restrict__ iext,
+                                                     const float* __restrict__ ohist, int hist_cap,
+                                                     Ext* __restrict__ ext, int* __restrict__ partial)
 {
-    __shared__ int s_wsum[4];
+    static_assert(SCAN_CHUNK == 256, "four lanes per extremum, 1024 lanes per workgroup");
+    __shared__ int s_wsum[16];
     __shared__ int s_ps[PS_MAX_OCT + 1];
     const int      n_oct = pdp->n_oct;
     if (threadIdx.x == 0) ext_prefix(ct, sc, n_oct, s_ps);
     __syncthreads();
     const int total = s_ps[n_oct];
-    const int base = blockIdx.x * SCAN_CHUNK;
-    if (base >= total) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g0 = base + tid * SCAN_ITEMS;
-    int       cnt[SCAN_ITEMS];
-    int       self = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const int g = g0 + k;
-        cnt[k] = 0;
-        if (g < total) {
-            /* the second half of ori_par for extremum g, then its Extremum record (sift_extremum.h:40-51) */
-            int o = 0;
-            while (o + 1 < n_oct && g >= s_ps[o + 1]) o++;
-            const InitExt ie = iext[(size_t)o * sc.max_extrema + (g - s_ps[o])];
-            Ext           e;
-            e.xpos = ie.xpos;
-            e.ypos = ie.ypos;
-            e.lpos = ie.lpos;
-            e.sigma = ie.sigma;
-            e.octave = o;
-            e.idx_ori = 0;
-            /* beyond the histogram buffer (the host grows it and re-runs the stages): no orientation */
-            e.num_ori = (g < hist_cap) ? ori_peaks(ohist + (size_t)g * PS_ORI_NBINS, e.orientation) : 0;
-            if (g >= hist_cap)
-                for (int q = 0; q < POPSIFT_HIP_ORI_MAX; q++) e.orientation[q] = 0.0f;
-            ext[g] = e;
-            cnt[k] = e.num_ori;
-        }
-        self += cnt[k];
-    }
+    const int j = tid & 3;
+    /* the launch is sized for the device, not for the capacity of the lists: workgroups stride over the chunks */
+    for (int chunk = blockIdx.x; chunk * SCAN_CHUNK < total; chunk += gridDim.x) {
+    const int  base = chunk * SCAN_CHUNK;
+    const int  g = base + (tid >> 2);
+    const bool valid = g < total;
+    const int  gc = min(g, total - 1); /* lanes beyond the list compute along (the quad exchanges need them) */
+    /* the second half of ori_par for extremum g, then its Extremum record (sift_extremum.h:40-51) */
+    int o = 0;
+    while (o + 1 < n_oct && gc >= s_ps[o + 1]) o++;
+    const InitExt ie = iext[(size_t)o * sc.max_extrema + (gc - s_ps[o])];
+    Ext           e;
+    e.xpos = ie.xpos;
+    e.ypos = ie.ypos;
+    e.lpos = ie.lpos;
+    e.sigma = ie.sigma;
+    e.octave = o;
+    e.idx_ori = 0;
+    /* beyond the histogram buffer (the host grows it and re-runs the stages): no orientation */
+    const bool have = gc < hist_cap;
+    const int  n = ori_peaks_quad(ohist + (size_t)min(gc, max(hist_cap - 1, 0)) * PS_ORI_NBINS, j, have, e.orientation);
+    e.num_ori = have ? n : 0;
+    if (!have)
+        for (int q = 0; q < POPSIFT_HIP_ORI_MAX; q++) e.orientation[q] = 0.0f;
+    const int self = (valid && j == 0) ? e.num_ori : 0;
+
     int incl = self;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -479,13 +527,13 @@ __global__ __launch_bounds__(256) void k_scan_local(const PyrDesc* __restrict__ 
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wave; w++) woff += s_wsum[w];
-    int excl = woff + incl - self;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (g0 + k < total) ext[g0 + k].idx_ori = excl; /* chunk-local for now */
-        excl += cnt[k];
+    if (valid && j == 0) {
+        e.idx_ori = woff + incl - self; /* chunk-local for now */
+        ext[g] = e;
     }
-    if (tid == 255) partial[blockIdx.x] = excl;
+    if (tid == 1023) partial[chunk] = woff + incl;
+    __syncthreads(); /* s_wsum is reused by the next chunk */
+    }
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc,
@@ -508,12 +556,22 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
     }
     __syncthreads();
     const int total = s_ps[PS_MAX_OCT];
-    const int base = blockIdx.x * SCAN_CHUNK;
-    if (base >= total && blockIdx.x != 0) return;
+    const int nb = (total + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nb == 0 && blockIdx.x == 0 && tid == 0) { /* no extrema at all: the counters still have to be written */
+        ct->ori_total = 0;
+        ct->ext_total = 0;
+        for (int o = 0; o < PS_MAX_OCT; o++) {
+            ct->ext_ct[o] = 0;
+            ct->ext_ps[o] = 0;
+        }
+    }
+    /* the launch is sized for the device, not for the capacity of the lists: workgroups stride over the chunks */
+    for (int chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+    const int base = chunk * SCAN_CHUNK;
 
     /* offset of this chunk = sum of the partials of all preceding chunks */
     int acc = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += 256) acc += partial[b];
+    for (int b = tid; b < chunk; b += 256) acc += partial[b];
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
     if (lane == 0) s_red[wave] = acc;
@@ -557,15 +615,16 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
                 if (g == s_ps[o] && s_ps[o + 1] > s_ps[o]) ct->ori_ps[o] = idx;
         }
     }
-    const int nb = (total + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    if (tid == 0 && ((int)blockIdx.x == nb - 1 || (nb == 0 && blockIdx.x == 0))) {
-        ct->ori_total = (nb > 0) ? offset + partial[blockIdx.x] : 0;
+    if (tid == 0 && chunk == nb - 1) {
+        ct->ori_total = offset + partial[chunk];
         ct->ext_total = total;
         for (int o = 0; o < PS_MAX_OCT; o++) {
             /* the reference clamps with atomicMin in the extrema kernel, s_extrema.cu:558 */
             ct->ext_ct[o] = (o < n_oct) ? min(ct->ext_ct[o], sc.max_extrema) : 0;
             ct->ext_ps[o] = s_ps[o];
         }
+    }
+    __syncthreads(); /* s_red is reused by the next chunk */
     }
 }
 
@@ -1238,8 +1297,9 @@ hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, co
                        int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot,
                        popsift_hip_feature* feats, int desc_cap, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan_local, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_chunks), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, feats, desc_cap);
+    /* n_chunks is the capacity of the lists; a 1080p image fills ~300 chunks */
+    hipLaunchKernelGGL(k_scan_local, dim3(std::min(n_chunks, 512)), dim3(1024), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
+    hipLaunchKernelGGL(k_scan_apply, dim3(std::min(n_chunks, 1024)), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, feats, desc_cap);
     return hipGetLastError();
 }
 

@@ -1,36 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- Mpix/s of SIFT extraction on synthetic 1920x1080 grayscale (BASELINE.json config 2).
+"""bench.py -- Mpix/s of SIFT extraction on synthetic 1920x1080 grayscale (BASELINE.json config 2 / 4).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A "step" is one pass of the extraction hot path over one
-batch of --batch synthetic images per GPU (inputs already resident in HBM;
---contexts extraction contexts, each with its own HIP stream, work through the
-batch with one image in flight per context; results left device resident like
-the reference's FeaturesDev).  Images are independent, so ranks
-never talk on the data path (weak scaling, no RCCL); torch.distributed is used
-for the barriers around the timed region and the MAX over ranks only.
+One process per GPU.  Started WITHOUT a torch.distributed environment and with --gpus N > 1, this script starts its
+N rank processes itself (before it has imported torch or touched HIP) and relays rank 0's line.
+
+A "step" is one pass of the extraction hot path over one batch of --batch synthetic images per GPU (inputs already
+resident in HBM; --contexts extraction contexts, each with its own HIP stream, work through the batch with one image
+in flight per context; results left device resident like the reference's FeaturesDev).  Images are independent, so
+ranks never talk on the data path (weak scaling, no RCCL); torch.distributed is used for the barriers around the
+timed region and the MAX over ranks only.
 
 Rank 0 prints ONE JSON line with the driver contract fields plus
-  roofline     -- the blur-level kernel (k_blur_tile), timed live with HIP events
-                  on the kernel's own stream (C-ABI profile mode)
-  cpu_baseline -- the CPU oracle (kind "port") on a bounded sample, N=1 only
+  roofline      -- the WHOLE pipeline of one image against the HBM roofline (B_alg / T_dev, T_dev from
+                   HIP events on the context's stream), with a `kernels` list: per stage its device time (HIP events
+                   between the launches, C-ABI profile mode 2), share, bound, achieved / peak / frac and the HBM
+                   traffic the rocprofv3 counter passes measured for it (profiles/r02_kernel_counters.json)
+  cpu_baseline  -- the CPU oracle (kind "port") on a bounded sample, N=1 only
+  sparse_image  -- the same pipeline on a keypoint-sparse image (about 2 features per 1000 pixels), where the pyramid
+                   -- the part `north_star` calls bandwidth-bound -- carries the time
+  legs_s        -- wall time of every leg of this run (the timed region is `timed`)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
-
-import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 W, H = 1920, 1080
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINST = 1228.8    # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -43,20 +49,41 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="timed loop only: no roofline / host-to-host / CPU legs (A/B runs)")
     ap.add_argument("--only-roofline", action="store_true",
-                    help="run only the single-context roofline pass (the command profiles/ *_roofline_pass* was taken with)")
+                    help="run only the single-context passes (the command the profiles/ *_single_image* files were taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
     return ap.parse_args()
 
 
-def blur_traffic():
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this configuration
-    (FETCH_SIZE x2 + WRITE_SIZE, separate passes; tools/collect_profiles.sh -> profiles/blur_traffic.json).
-    PMC collection cannot run inside the timed process, so the committed measurement is quoted."""
+def spawn_ranks(args):
+    """--gpus N without a torch.distributed environment: be the launcher.  Nothing here imports torch or touches the
+    GPU, so no process that has initialised HIP is ever replaced or forked."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def kernel_counters():
+    """Per-stage HBM traffic and instruction counts from the rocprofv3 counter passes of this configuration
+    (tools/collect_profiles.sh -> profiles/r02_kernel_counters.json; FETCH_SIZE x2 + WRITE_SIZE, separate passes).
+    Counters cannot be collected inside the timed process, so the committed measurement is quoted."""
     try:
-        with open(os.path.join(HERE, "profiles", "blur_traffic.json")) as f:
-            return round(json.load(f)["traffic_bytes_per_launch"], 1)
+        with open(os.path.join(HERE, "profiles", "r02_kernel_counters.json")) as f:
+            return json.load(f)
     except Exception:
-        return None
+        return {}
 
 
 class Workers:
@@ -102,11 +129,47 @@ class Workers:
             t.join()
 
 
-ROOT = HERE
+def b_alg(rep, w, h, in_bytes=1):
+    """input read once, every Gaussian plane written and read once, every DoG plane written and read
+    once, outputs written once.  The DoG planes are not stored by this build (their consumers subtract Gaussian planes),
+    which moves fewer bytes; the survey's formula is kept as the yardstick."""
+    L = 6
+    return w * h * in_bytes + 4.0 * rep.pyramid_pixels * (2 * L + 2 * (L - 1)) + 72.0 * rep.ext_total + 512.0 * rep.ori_total
+
+
+def single_image(ctx, ptr, hip, n=5):
+    """T_dev (HIP events, first to last kernel, median of n) and the stage times (profile mode 2) of one image."""
+    import numpy as np
+    lat = []
+    for _ in range(n):
+        ctx.submit_dev(ptr, W, H, W)
+        ctx.wait()
+        lat.append(ctx.report().ms_device)
+    ctx.set_profile(2)
+    st = []
+    for _ in range(n):
+        ctx.submit_dev(ptr, W, H, W)
+        ctx.wait()
+        st.append(list(ctx.report().ms_stage)[:len(hip.STAGES)])
+    ctx.set_profile(0)
+    rep = ctx.report()
+    return float(np.median(lat)), [float(x) for x in np.median(np.array(st), 0)], rep
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    legs = {}
+    t_leg = time.perf_counter()
+
+    def leg(name):
+        nonlocal t_leg
+        now = time.perf_counter()
+        legs[name] = round(legs.get(name, 0.0) + now - t_leg, 3)
+        t_leg = now
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -115,8 +178,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: WORLD_SIZE=%d but --gpus %d; launch with torch.distributed.run" % (world, args.gpus),
-                  file=sys.stderr)
+            print("bench.py: WORLD_SIZE=%d but --gpus %d: reporting %d ranks" % (world, args.gpus, world), file=sys.stderr)
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the extraction path has no CPU fallback)")
@@ -124,6 +186,10 @@ def main():
     # BENCH_BACKEND=gloo swaps RCCL for gloo, to exercise the N>1 control path without N GPUs.
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible (one process per GPU; set "
+                         "BENCH_FORCE_DEVICE=0 BENCH_BACKEND=gloo to rehearse the control path on one card)"
+                         % (rank, local_rank, torch.cuda.device_count()))
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -134,13 +200,19 @@ def main():
             dist.init_process_group(backend=backend)
 
     from popsift_amd import _capi as hip
+    from popsift_amd.shard import reduce_stats, shard_indices
     from popsift_amd.synth import synth
+    leg("import_init")
 
     B = 1 if args.only_roofline else args.batch
-    # config 4 seeds 100.. for batches; config 2's own image (seed 2) is image 0 of rank 0
-    U = min(B, 16)  # distinct images per rank (0.5 s of host time each to synthesise); the batch cycles through them
-    seeds = [2 if (rank == 0 and i == 0) else 100 + rank * U + i for i in range(U)]
+    # BASELINE.json config 4: a batch of seeds 100.. dealt to the ranks (popsift_amd/shard.py: image i -> rank i mod N);
+    # config 2's own image (seed 2) is image 0 of rank 0.  A rank synthesises min(B, 16) distinct images (0.5 s of host
+    # time each) and cycles through them.
+    U = min(B, 16)
+    mine = shard_indices(world * U, rank, world)
+    seeds = [2 if (rank == 0 and k == 0) else 100 + i for k, i in enumerate(mine)]
     host_imgs = [synth(s, W, H) for s in seeds]
+    leg("synth")
     dev_imgs = [torch.from_numpy(im).cuda(local_rank) for im in host_imgs]  # inputs resident in HBM
     ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
     C = max(1, min(args.contexts, B))
@@ -154,60 +226,76 @@ def main():
 
     if args.only_roofline:
         args.steps, args.warmup = 1, 0
+    leg("setup")
     for _ in range(args.warmup):
         workers.step()
     barrier()
+    leg("warmup")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         workers.step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    leg("timed")
     workers.close()
 
-    feats = sum(workers.feats)   # of one step
-    descs = sum(workers.descs)
-    rdev = "cuda" if backend == "nccl" else "cpu"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-    cnt = torch.tensor([feats, descs], dtype=torch.float64, device=rdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    feats_step, descs_step = float(cnt[0].item()), float(cnt[1].item())
-
+    # MAX over ranks of the time, SUM of the counters (popsift_amd/shard.py)
+    elapsed, (feats_step, descs_step) = reduce_stats(dist if world > 1 else None, elapsed,
+                                                     (sum(workers.feats), sum(workers.descs)),
+                                                     device="cuda" if backend == "nccl" else "cpu")
     images = args.steps * B * world
     mpix = images * W * H / 1e6
     value = mpix / elapsed
 
     extra = {}
-    if rank == 0 and args.quick:
-        print(json.dumps({"value": round(value, 2), "unit": "Mpix/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                          "steps": args.steps, "quick": True}), flush=True)
-    elif rank == 0:
-        # ---- single-image device latency (hipEvents, first to last kernel) -------------
+    roofline = cpu = None
+    if rank == 0 and not args.quick:
         c0 = ctxs[0]
-        lat = []
-        for _ in range(5):
-            c0.submit_dev(ptrs[0], W, H, W)
-            c0.wait()
-            lat.append(c0.report().ms_device)
-        ms_dev = float(np.median(lat))
-        rep = c0.report()
-        # planes: 6 Gaussian written + read by the next level; DoG on the fly: detection reads the 6 Gaussian planes again
-        # (POPSIFT_HIP_DOG_FLY=0: 5 DoG planes written and read instead)
-        plane_passes = (2 * 6 + 6) if os.environ.get("POPSIFT_HIP_DOG_FLY", "1") != "0" else (2 * 6 + 2 * 5)
-        b_alg = W * H * 1 + 4.0 * rep.pyramid_pixels * plane_passes + 52.0 * rep.ext_total + 512.0 * rep.ori_total
-        extra["single_image"] = {
-            "ms_device": round(ms_dev, 4), "features": rep.ext_total, "descriptors": rep.ori_total,
-            "pipeline_alg_GBps": round(b_alg / (ms_dev * 1e-3) / 1e9, 1),
-            "pipeline_frac_of_8TBps": round(b_alg / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        # ---- one image on an otherwise idle GPU: T_dev, stage times, pipeline roofline ------------------------------
+        ms_dev, stage_ms, rep = single_image(c0, ptrs[0], hip)
+        bytes_alg = b_alg(rep, W, H)
+        achieved = bytes_alg / (ms_dev * 1e-3) / 1e9
+        ctr = kernel_counters()
+        kernels = []
+        ssum = sum(stage_ms) or 1.0
+        for name, ms in zip(hip.STAGES, stage_ms):
+            k = {"stage": name, "ms": round(ms, 4), "share": round(ms / ssum, 3)}
+            c = ctr.get(name, {})
+            k["traffic"] = c.get("hbm_bytes")
+            if name in ("orientation", "descriptor", "scan"):
+                # VALU-issue bound: wave64 vector instructions per second against 1 per 2 cycles per SIMD
+                k["bound"] = "valu"
+                if c.get("valu_insts") and ms > 0:
+                    k["achieved"] = round(c["valu_insts"] / (ms * 1e-3) / 1e9, 1)
+                    k["peak"], k["unit"] = VALU_PEAK_GINST, "G wave-instr/s"
+                    k["frac"] = round(k["achieved"] / VALU_PEAK_GINST, 4)
+            else:
+                k["bound"] = "hbm"
+                alg = {"pyramid": W * H + 4.0 * rep.pyramid_pixels * 2 * 6,           # every plane written + read once
+                       "detect": 4.0 * rep.pyramid_pixels * 6,                          # six Gaussian planes read once
+                       "refine": None}[name]
+                if alg and ms > 0:
+                    k["alg_bytes"] = alg
+                    k["achieved"] = round(alg / (ms * 1e-3) / 1e9, 1)
+                    k["peak"], k["unit"] = HBM_PEAK_GBPS, "GB/s"
+                    k["frac"] = round(k["achieved"] / HBM_PEAK_GBPS, 4)
+            kernels.append(k)
+        traffic = sum(k["traffic"] for k in kernels if k.get("traffic")) or None
+        roofline = {
+            "kernel": "whole pipeline, one 1920x1080 image (pyramid -> detect -> refine -> orientation -> descriptors)",
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "alg_bytes_per_image": bytes_alg, "ms_device": round(ms_dev, 4),
+            "steady_state": {"ms_per_image": round(elapsed / (args.steps * B) * 1e3, 4),
+                             "achieved": round(bytes_alg * args.steps * B / elapsed / 1e9, 1),
+                             "frac": round(bytes_alg * args.steps * B / elapsed / 1e9 / HBM_PEAK_GBPS, 4)},
+            "dominant": max(kernels, key=lambda k: k["ms"])["stage"], "kernels": kernels,
         }
-        # ---- roofline of the dominant (HBM-bound) kernel --------------------------------
-        # k_blur_tile<HALO,0,64>: the fused "Gaussian level + DoG" launches of the large octaves
-        # (5 per such octave; 12 algorithmic bytes per pixel: read plane l-1, write plane l + DoG l-1).
-        # Timed with HIP events on the context's own stream (C-ABI profile mode).
-        c0.set_profile(True)
+        extra["single_image"] = {"ms_device": round(ms_dev, 4), "features": rep.ext_total, "descriptors": rep.ori_total}
+        leg("single_image")
+        # ---- the blur level launches alone (profile mode 1: every launch timed) -----------------------------------
+        c0.set_profile(1)
         big_ms = big_bytes = all_ms = all_bytes = 0.0
         big_n = all_n = 0
         for _ in range(5):
@@ -220,20 +308,34 @@ def main():
             all_ms += r.ms_blur
             all_bytes += r.blur_alg_bytes
             all_n += r.blur_launches
-        c0.set_profile(False)
-        if big_n == 0:
-            big_ms, big_bytes, big_n = all_ms, all_bytes, all_n
-        achieved = big_bytes / (big_ms * 1e-3) / 1e9 if big_ms > 0 else 0.0
-        roofline = {
-            "kernel": "k_blur_tile<HALO,0,64> (fused H+V Gaussian level, large octaves)", "bound": "hbm",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": blur_traffic(),
-            "launches": big_n, "avg_launch_us": round(big_ms * 1e3 / max(big_n, 1), 2),
-            "alg_bytes_per_launch": round(big_bytes / max(big_n, 1), 1),
-            "all_blur_launches": {"launches": all_n, "avg_launch_us": round(all_ms * 1e3 / max(all_n, 1), 2),
-                                  "achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1) if all_ms > 0 else 0.0},
-        }
-        # ---- PCIe-inclusive end-to-end rate (host image in, host features out) -----------
+        c0.set_profile(0)
+        if big_n:
+            roofline["blur_level_launch"] = {
+                "kernel": "k_blur_tile<HALO,0,64> (fused H+V Gaussian level, octave 0)", "launches": big_n,
+                "avg_launch_us": round(big_ms * 1e3 / big_n, 2), "alg_bytes_per_launch": round(big_bytes / big_n, 1),
+                "achieved": round(big_bytes / (big_ms * 1e-3) / 1e9, 1),
+                "frac": round(big_bytes / (big_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "all_blur_launches": {"launches": all_n, "avg_launch_us": round(all_ms * 1e3 / max(all_n, 1), 2),
+                                      "achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1) if all_ms > 0 else 0.0}}
+        leg("blur_profile")
+        # ---- a keypoint-sparse image: the pyramid-bound regime ------------------------------------------------------
+        if not args.only_roofline:
+            sp = hip.Context(hip.default_params(threshold=0.17), device=local_rank)
+            lat = []
+            for _ in range(5):
+                sp.submit_dev(ptrs[0], W, H, W)
+                sp.wait()
+                lat.append(sp.report().ms_device)
+            ms_sp = float(np.median(lat))
+            rs = sp.report()
+            bs = b_alg(rs, W, H)
+            extra["sparse_image"] = {"threshold": 0.17, "features": rs.ext_total, "descriptors": rs.ori_total,
+                                     "features_per_1000_px": round(rs.ext_total / (W * H / 1000.0), 2),
+                                     "ms_device": round(ms_sp, 4), "pipeline_alg_GBps": round(bs / (ms_sp * 1e-3) / 1e9, 1),
+                                     "pipeline_frac_of_8TBps": round(bs / (ms_sp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+            sp.close()
+            leg("sparse_image")
+        # ---- PCIe-inclusive end-to-end rate (host image in, host features out), one context -----------------------
         t1 = time.perf_counter()
         n_e2e = 0 if args.only_roofline else 8
         for k in range(n_e2e):
@@ -241,21 +343,40 @@ def main():
             c0.fetch()
         if n_e2e:
             extra["host_to_host_single_ctx_mpix_s"] = round(n_e2e * W * H / 1e6 / (time.perf_counter() - t1), 1)
+        leg("h2h_single_ctx")
 
-        # the same through the drop-in C++ API (PopSift::enqueue ... SiftJob::get, 4 contexts, pinned result pool):
-        # a child process, so that its GPU contexts do not share this one's; reported, never `value`
-        exe = os.path.join(ROOT, "popsift_amd", "popsift-bench")
-        if world == 1 and not args.only_roofline and os.path.exists(exe):
-            import subprocess
+    for c in ctxs:
+        c.close()
+    del dev_imgs
+    torch.cuda.empty_cache()
+    if world > 1:
+        dist.barrier()          # every rank has released its contexts: the C++ leg below gets the GPUs to itself
+
+    if rank == 0 and not args.quick and not args.only_roofline:
+        # the drop-in C++ API (PopSift::enqueue ... SiftJob::get, pinned result pool) over EVERY GPU of the job:
+        # a child process with one worker pool over POPSIFT_DEVICES; reported, never `value`
+        exe = os.path.join(HERE, "popsift_amd", "popsift-bench")
+        if os.path.exists(exe):
+            devs = ",".join(str(d) for d in range(world)) if os.environ.get("BENCH_FORCE_DEVICE") is None else \
+                ",".join([os.environ["BENCH_FORCE_DEVICE"]] * world)
             try:
-                r = subprocess.run([exe, "--images", "64", "--inflight", "16"], capture_output=True, text=True, timeout=120,
-                                   env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE="4", POPSIFT_DEVICES=str(local_rank)))
+                import tempfile
+                tmp = tempfile.mkdtemp(prefix="popsift_bench_")
+                pgms = []
+                for k, im in enumerate(host_imgs[:8]):   # the synth.py images of this workload, as PGM files
+                    pgms.append(os.path.join(tmp, "img%d.pgm" % k))
+                    with open(pgms[-1], "wb") as f:
+                        f.write(b"P5\n%d %d\n255\n" % (W, H))
+                        f.write(im.tobytes())
+                r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(16 * world), "--pgm", ",".join(pgms)],
+                                   capture_output=True, text=True, timeout=180,
+                                   env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE="4", POPSIFT_DEVICES=devs))
                 extra["host_to_host_cpp_api"] = json.loads(r.stdout.strip().splitlines()[-1])
+                extra["host_to_host_cpp_api"]["devices"] = devs
             except Exception as e:  # a reported extra: never fail the bench line over it
                 extra["host_to_host_cpp_api"] = {"error": str(e)[:200]}
-
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline and not args.only_roofline:
+        leg("cpp_api")
+        if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O  # checker / reported baseline only
             # a 1-GPU box grants a 16-core CPU share; more OpenMP threads than that only oversubscribe
             cores = min(os.cpu_count() or 1, 16)
@@ -269,25 +390,31 @@ def main():
                    "kind": "port",
                    "sample": "%d x 1920x1080 synthetic images, full pipeline, CPU restatement of PopSift "
                              "(oracle/, OpenMP, %d threads)" % (args.cpu_images, cores)}
-        out = {
-            "metric": "Mpix/s SIFT extract on 1920x1080 (keypoints+descriptors)",
-            "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "1920x1080 u8 grayscale, default popsift::Config (2x upscale, 9 octaves, "
-                                   "3 levels, PopSift mode, loop descriptor, RootSift)",
-                       "images_per_step_per_gpu": B, "distinct_images_per_gpu": U, "in_flight_contexts_per_gpu": C,
-                       "results": "device resident (features + descriptors)"},
-            "features_per_s": round(feats_step * args.steps / elapsed, 1),
-            "descriptors_per_s": round(descs_step * args.steps / elapsed, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        out.update(extra)
+            leg("cpu_baseline")
+
+    if rank == 0:
+        if args.quick:
+            out = {"value": round(value, 2), "unit": "Mpix/s", "n_gpus": world,
+                   "ms_per_step": round(elapsed / args.steps * 1e3, 4), "steps": args.steps, "quick": True}
+        else:
+            out = {
+                "metric": "Mpix/s SIFT extract on 1920x1080 (keypoints+descriptors)",
+                "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": "1920x1080 u8 grayscale, default popsift::Config (2x upscale, 9 octaves, "
+                                       "3 levels, PopSift mode, loop descriptor, RootSift)",
+                           "images_per_step_per_gpu": B, "distinct_images_per_gpu": U, "in_flight_contexts_per_gpu": C,
+                           "results": "device resident (features + descriptors)"},
+                "features_per_s": round(feats_step * args.steps / elapsed, 1),
+                "descriptors_per_s": round(descs_step * args.steps / elapsed, 1),
+                "roofline": roofline, "cpu_baseline": cpu,
+            }
+            out.update(extra)
+            out["legs_s"] = legs
         print(json.dumps(out), flush=True)
 
-    for c in ctxs:
-        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -112,7 +112,17 @@ typedef struct popsift_hip_report {
     double  big_alg_bytes;
     float   ms_big;
     int32_t big_launches;
+    /* profile mode 2: device time of the stages of one image, HIP events on the context's stream between the
+     * launches (POPSIFT_HIP_STAGE_*); 0 when not collected */
+    float   ms_stage[8];
 } popsift_hip_report;
+enum { POPSIFT_HIP_STAGE_PYRAMID = 0,     /* every k_blur_tile launch                              */
+       POPSIFT_HIP_STAGE_DETECT = 1,      /* k_detect (both passes)                                */
+       POPSIFT_HIP_STAGE_REFINE = 2,      /* k_refine (+ the grid filter when enabled)             */
+       POPSIFT_HIP_STAGE_ORIENTATION = 3, /* k_orientation                                         */
+       POPSIFT_HIP_STAGE_SCAN = 4,        /* k_scan_local + k_scan_apply                           */
+       POPSIFT_HIP_STAGE_DESCRIPTOR = 5,  /* the descriptor kernel                                 */
+       POPSIFT_HIP_STAGE_COUNT = 6 };
 
 typedef struct popsift_hip_ctx popsift_hip_ctx;
 
@@ -221,7 +231,7 @@ int popsift_hip_match_sets(const popsift_hip_devfeatures* l, const popsift_hip_d
 int popsift_hip_get_report(const popsift_hip_ctx* ctx, popsift_hip_report* rep);
 /* profile != 0: bracket every blur-level launch with HIP events (serialises the
  * octave streams; used by bench.py for the roofline object only). */
-int popsift_hip_set_profile(popsift_hip_ctx* ctx, int profile);
+int popsift_hip_set_profile(popsift_hip_ctx* ctx, int profile); /* 0 off, 1 blur launches, 2 stages */
 
 /* Debug / parity hooks (replace Octave::download_and_save_array,
  * sift_octave.cu:110-187).  kind: 0 = Gaussian plane, 1 = DoG plane. */

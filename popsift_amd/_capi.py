@@ -48,6 +48,7 @@ class Report(C.Structure):
         ("ms_device", C.c_float), ("ms_blur", C.c_float), ("blur_launches", C.c_int32),
         ("blur_alg_bytes", C.c_double), ("pyramid_pixels", C.c_double),
         ("big_alg_bytes", C.c_double), ("ms_big", C.c_float), ("big_launches", C.c_int32),
+        ("ms_stage", C.c_float * 8),
     ]
 
 
@@ -112,6 +113,7 @@ SYMBOLS = [
     ("popsift_hip_rerun_keypoint_stages", C.c_int, [_vp]),
     ("popsift_hip_debug_set", C.c_int, [_vp, C.c_int, C.c_int]),
 ]
+STAGES = ("pyramid", "detect", "refine", "orientation", "scan", "descriptor")
 DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC = 1, 2, 3, 4
 
 _lib = None
@@ -291,8 +293,9 @@ class Context:
         self._chk(lib().popsift_hip_get_report(self._h, C.byref(r)), "popsift_hip_get_report")
         return r
 
-    def set_profile(self, on):
-        self._chk(lib().popsift_hip_set_profile(self._h, 1 if on else 0), "popsift_hip_set_profile")
+    def set_profile(self, mode):
+        """0 off, 1 (True): every blur launch timed, 2: stage times (report().ms_stage)"""
+        self._chk(lib().popsift_hip_set_profile(self._h, int(mode)), "popsift_hip_set_profile")
 
     def octave_dims(self, o):
         w, h = C.c_int(), C.c_int()

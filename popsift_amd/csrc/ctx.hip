@@ -57,6 +57,7 @@ struct popsift_hip_ctx {
     SiftConsts         sc{};
     hipStream_t        stream = nullptr;
     hipEvent_t         ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t         ev_stage[POPSIFT_HIP_STAGE_COUNT + 1] = {}; /* profile mode 2: boundaries of the stages */
 
     /* image geometry */
     int  in_w = 0, in_h = 0;
@@ -368,7 +369,7 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
 
 int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int tile_h, double alg_bytes)
 {
-    if (c->profile) {
+    if (c->profile == 1) {
         if (c->blur_events_used == c->blur_events.size()) {
             EventPair ep;
             HIP_TRY(c, hipEventCreate(&ep.a));
@@ -390,52 +391,93 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int t
     return 0;
 }
 
-/* Pyramid::build_pyramid default branch (s_pyramid_build.cu:549-588) */
+/* arguments of the launch that produces plane `level` (>= 1) of octave o from plane level - 1 */
+BlurArgs level_args(const popsift_hip_ctx* c, int o, int level)
+{
+    const PyrDesc& pd = c->pd;
+    const OctDesc& od = pd.o[o];
+    BlurArgs       a{};
+    a.w = od.w;
+    a.h = od.h;
+    a.pitch = od.pitch;
+    const int thd = blur_tile_h(od.w, od.h), twd = blur_tile_w();
+    a.tiles_x = (od.w + twd - 1) / twd;
+    a.tiles_y = (od.h + thd - 1) / thd;
+    memcpy(a.taps.g, &c->tab.filter[level * PS_GA], sizeof(a.taps.g));
+    a.dst = od.data + level * od.plane_stride;
+    a.src = od.data + (level - 1) * od.plane_stride;
+    a.dog = pd.dog_fly ? nullptr : od.dog + (level - 1) * od.plane_stride;
+    a.in = nullptr;
+    /* level L-3 also writes every second pixel as plane 0 of the next octave (get_by_2_pick_every_second) */
+    a.next0 = (level == pd.L - 3 && o + 1 < pd.n_oct) ? pd.o[o + 1].data : nullptr;
+    a.next_pitch = (o + 1 < pd.n_oct) ? pd.o[o + 1].pitch : 0;
+    return a;
+}
+
+/*
+ * Pyramid::build_pyramid default branch (s_pyramid_build.cu:549-588), one stream.  Launch order:
+ *   octave 0: level 0 (from the input image), levels 1 .. L-1;
+ *   octave o >= 1: levels 1 .. L-3 (level 0 came with level L-3 of octave o-1); the two last levels of octave o-1
+ *   (they feed nothing but detection) ride along with levels 1 and 2 of octave o in ONE launch (k_blur_duo) when both
+ *   octaves use 32-row tiles -- 3 instead of 5 dependent launches per small octave;
+ *   finally the two last levels of the last octave.
+ */
 int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch)
 {
     const PyrDesc& pd = c->pd;
-    const int      twd = blur_tile_w();
-    for (int o = 0; o < pd.n_oct; o++) {
-        const OctDesc& od = pd.o[o];
+    const int      L = pd.L;
+    auto single = [&](int o, int level) -> int {
+        const BlurArgs a = level_args(c, o, level);
+        const double   px = (double)pd.o[o].w * pd.o[o].h;
+        /* read plane l-1 once, write plane l (and DoG l-1 when it is stored) once: 8 (12) B / pixel */
+        return blur_launch(c, a, 0, c->tab.span[level], blur_tile_h(pd.o[o].w, pd.o[o].h), (pd.dog_fly ? 8.0 : 12.0) * px);
+    };
+    {
+        /* horiz_from_input_image, s_pyramid_build.cu:96-126 */
+        const OctDesc& od = pd.o[0];
         BlurArgs       a{};
         a.w = od.w;
         a.h = od.h;
         a.pitch = od.pitch;
-        const int thd = blur_tile_h(od.w, od.h);
+        const int thd = blur_tile_h(od.w, od.h), twd = blur_tile_w();
         a.tiles_x = (od.w + twd - 1) / twd;
         a.tiles_y = (od.h + thd - 1) / thd;
-        const double px = (double)od.w * od.h;
-        for (int level = 0; level < pd.L; level++) {
-            memcpy(a.taps.g, &c->tab.filter[level * PS_GA], sizeof(a.taps.g));
-            a.dst = od.data + level * od.plane_stride;
-            if (level == 0) {
-                if (o == 0) {
-                    /* horiz_from_input_image, s_pyramid_build.cu:96-126 */
-                    float shift = 0.5f;
-                    if (c->p.sift_mode == POPSIFT_HIP_SIFT_POPSIFT || c->p.sift_mode == POPSIFT_HIP_SIFT_VLFEAT)
-                        shift = 0.5f * powf(2.0f, c->p.upscale_factor - 0);
-                    a.src = nullptr;
-                    a.dog = nullptr;
-                    a.in = d_img;
-                    a.in_w = c->in_w;
-                    a.in_h = c->in_h;
-                    a.in_pitch = pitch;
-                    a.shift = shift;
-                    const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * px;
-                    if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
-                }
-                /* o > 0: level 0 was written by the previous octave's level L-3 launch (BlurArgs::next0) */
+        memcpy(a.taps.g, &c->tab.filter[0], sizeof(a.taps.g));
+        a.dst = od.data;
+        float shift = 0.5f;
+        if (c->p.sift_mode == POPSIFT_HIP_SIFT_POPSIFT || c->p.sift_mode == POPSIFT_HIP_SIFT_VLFEAT)
+            shift = 0.5f * powf(2.0f, c->p.upscale_factor - 0);
+        a.in = d_img;
+        a.in_w = c->in_w;
+        a.in_h = c->in_h;
+        a.in_pitch = pitch;
+        a.shift = shift;
+        /* weights of the linear upscale are exactly {0, 1/2}: k_blur_tile's copy / average path */
+        a.fast2x = (c->p.upscale_factor == 1.0f && shift == 1.0f && od.w == 2 * c->in_w && od.h == 2 * c->in_h) ? 1 : 0;
+        const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * (double)od.w * od.h;
+        if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
+    }
+    for (int level = 1; level < L; level++)
+        if (int rc = single(0, level)) return rc;
+    for (int o = 1; o < pd.n_oct; o++) {
+        /* per-launch profiling keeps one kernel per event pair */
+        const bool pair = c->profile != 1 && o >= 2 && blur_tile_h(pd.o[o].w, pd.o[o].h) == 32 &&
+                          blur_tile_h(pd.o[o - 1].w, pd.o[o - 1].h) == 32;
+        for (int level = 1; level <= L - 3; level++) {
+            const int trail = L - 3 + level; /* L-2, L-1 of the octave before */
+            if (pair && level <= 2) {
+                const BlurArgs a = level_args(c, o, level), b = level_args(c, o - 1, trail);
+                HIP_TRY(c, launch_blur_duo(a, c->tab.span[level], b, c->tab.span[trail], c->stream));
             } else {
-                a.src = od.data + (level - 1) * od.plane_stride;
-                a.dog = pd.dog_fly ? nullptr : od.dog + (level - 1) * od.plane_stride;
-                a.in = nullptr;
-                a.next0 = (level == pd.L - 3 && o + 1 < pd.n_oct) ? pd.o[o + 1].data : nullptr;
-                a.next_pitch = (o + 1 < pd.n_oct) ? pd.o[o + 1].pitch : 0;
-                /* read plane l-1 once, write plane l (and DoG l-1 when it is stored) once: 8 (12) B / pixel */
-                if (int rc = blur_launch(c, a, 0, c->tab.span[level], thd, (pd.dog_fly ? 8.0 : 12.0) * px)) return rc;
+                if (int rc = single(o, level)) return rc;
+                if (!pair && level <= 2 && o >= 2)
+                    if (int rc = single(o - 1, trail)) return rc;
             }
         }
     }
+    if (pd.n_oct >= 2)
+        for (int level = L - 2; level < L; level++)
+            if (int rc = single(pd.n_oct - 1, level)) return rc;
     return 0;
 }
 
@@ -444,20 +486,27 @@ InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iex
 
 int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
+    const bool stages = (c->profile == 2);
+    auto       mark = [&](int k) -> hipError_t { return stages ? hipEventRecord(c->ev_stage[k], c->stream) : hipSuccess; };
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
+    HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DETECT)); /* = end of the pyramid stage */
     HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_ovf, c->d_iext,
-                              c->stream));
+                              c->stream, stages ? c->ev_stage[POPSIFT_HIP_STAGE_REFINE] : nullptr));
     if (c->sc.filter_max > 0) {
         /* Pyramid::orientation's filter hook (s_orientation.cu:353-367); the 10 % test is taken on the device */
         HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->d_ct, c->d_iext, c->d_iext2, c->d_fstate, c->d_fhist, c->stream));
     }
+    HIP_TRY(c, mark(POPSIFT_HIP_STAGE_ORIENTATION));
     HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->kp_waves,
                                   c->stream));
+    HIP_TRY(c, mark(POPSIFT_HIP_STAGE_SCAN));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->d_ext, c->d_partial,
                            std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_feats, c->desc_cap, c->stream));
+    HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DESCRIPTOR));
     HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->kp_waves,
                                   c->stream));
+    HIP_TRY(c, mark(POPSIFT_HIP_STAGE_COUNT));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
@@ -501,6 +550,7 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
     }
     c->blur_events_used = 0;
     HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
+    if (c->profile == 2) HIP_TRY(c, hipEventRecord(c->ev_stage[POPSIFT_HIP_STAGE_PYRAMID], c->stream));
     if (int rc = enqueue_pyramid(c, d_img, is_f32, dpitch)) return rc;
     if (int rc = enqueue_keypoint_stages(c)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
@@ -555,6 +605,12 @@ int finish(popsift_hip_ctx* c)
     r.ori_total = std::min(c->h_ct->ori_total, c->desc_cap);
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) r.ms_device = ms;
+    for (int k = 0; k < 8; k++) r.ms_stage[k] = 0.0f;
+    if (c->profile == 2)
+        for (int k = 0; k < POPSIFT_HIP_STAGE_COUNT; k++) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, c->ev_stage[k], c->ev_stage[k + 1]) == hipSuccess) r.ms_stage[k] = t;
+        }
     r.ms_blur = 0.0f;
     r.blur_launches = 0;
     r.blur_alg_bytes = 0.0;
@@ -719,6 +775,7 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
         HIP_TRY(c, hipEventCreate(&c->ev_end));
+        for (int k = 0; k <= POPSIFT_HIP_STAGE_COUNT; k++) HIP_TRY(c, hipEventCreate(&c->ev_stage[k]));
         HIP_TRY(c, hipMalloc((void**)&c->d_ct, sizeof(Counters)));
         HIP_TRY(c, hipMalloc((void**)&c->d_pd, sizeof(PyrDesc)));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_pd, sizeof(PyrDesc), hipHostMallocDefault));
@@ -747,6 +804,8 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
         (void)hipEventDestroy(ep.a);
         (void)hipEventDestroy(ep.b);
     }
+    for (int k = 0; k <= POPSIFT_HIP_STAGE_COUNT; k++)
+        if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->d_input) (void)hipFree(c->d_input);
@@ -1085,7 +1144,7 @@ int popsift_hip_get_report(const popsift_hip_ctx* c, popsift_hip_report* rep)
 int popsift_hip_set_profile(popsift_hip_ctx* c, int profile)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
-    c->profile = profile ? 1 : 0;
+    c->profile = (profile == 2) ? 2 : (profile ? 1 : 0);
     return POPSIFT_HIP_OK;
 }
 

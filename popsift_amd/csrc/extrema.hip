@@ -606,7 +606,7 @@ static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
 }
 
 hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
-                          Counters* ct, int2* cand, int cand_cap, int* ovf, InitExt* iext, hipStream_t s)
+                          Counters* ct, int2* cand, int cand_cap, int* ovf, InitExt* iext, hipStream_t s, hipEvent_t mid)
 {
     if (pd.total_tiles <= 0) return hipSuccess;
     if (pd.levels < 2 || pd.levels > 9) return hipErrorInvalidValue;
@@ -614,6 +614,7 @@ hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
     switch (sc.sift_mode) {
     case POPSIFT_HIP_SIFT_OPENCV:
         launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
+        if (mid) (void)hipEventRecord(mid, s);
         if (pd.dog_fly)
             hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         else
@@ -621,6 +622,7 @@ hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
         break;
     case POPSIFT_HIP_SIFT_VLFEAT:
         launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
+        if (mid) (void)hipEventRecord(mid, s);
         if (pd.dog_fly)
             hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         else
@@ -628,6 +630,7 @@ hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
         break;
     default:
         launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
+        if (mid) (void)hipEventRecord(mid, s);
         if (pd.dog_fly)
             hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
         else

@@ -21,6 +21,7 @@ struct BlurArgs {
     const void*  in; /* input image (MODE 1: u8, MODE 2: f32)  */
     int          in_w, in_h, in_pitch;
     float        shift;
+    int          fast2x; /* level 0 only: the plane is the input stretched by exactly 2 with source coordinate X / 2 */
     Taps         taps;
     /* level L-3 only: level 0 of the next octave = every second pixel of this plane (get_by_2_pick_every_second,
      * s_pyramid_build.cu:50-71), written by the same launch; null otherwise */
@@ -31,12 +32,15 @@ struct BlurArgs {
 int        blur_tile_w();
 int        blur_tile_h(int w, int h); /* 32 or 64 rows, by plane size */
 hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s);
+/* two plane-to-plane level launches with 32-row tiles in one (small octaves) */
+hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, hipStream_t s);
 
 /* extrema.hip */
 hipError_t launch_dog_plane(float* dog, const float* upper, const float* lower, size_t n, hipStream_t s); /* debug / test downloads */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */
+/* mid: event recorded between detection and refinement (stage timing), or null */
 hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, int2* cand,
-                          int cand_cap, int* ovf, InitExt* iext, hipStream_t s);
+                          int cand_cap, int* ovf, InitExt* iext, hipStream_t s, hipEvent_t mid);
 
 /* keypoint.hip */
 /* ohist: 36 floats per extremum (the raw orientation histogram), hist_cap extrema */

@@ -20,6 +20,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "sift_types.h"
 #include "kernels.h"
 
@@ -85,8 +87,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
  *            DoG = new - old (old kept in registers since phase 2: the same lane
  *            owns the same 4x4 block in both passes)
  */
+template <int HALO, int TH>
+constexpr int blur_lds_floats()
+{
+    return (TH + 2 * HALO) * (TW + 2 * ((HALO + 3) & ~3));
+}
+
 template <int HALO, int MODE, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
+__device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, float* __restrict__ s_t)
 {
     constexpr int HP = (HALO + 3) & ~3;   /* left/right halo, padded to 16 B   */
     constexpr int SW = TW + 2 * HP;       /* LDS row pitch                     */
@@ -94,9 +102,7 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
     constexpr int NW = 1 + HP / 2;        /* H-pass window in 16 B chunks      */
     constexpr int VW = 4 + 2 * HALO;      /* V-pass window rows                */
 
-    __shared__ __attribute__((aligned(16))) float s_t[SR * SW];
-
-    const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int tile = xcd_remap(block, a.tiles_x * a.tiles_y);
     const int tx0 = (tile % a.tiles_x) * TW;
     const int ty0 = (tile / a.tiles_x) * TH;
     const int tid = threadIdx.x;
@@ -171,7 +177,80 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
         const int ys0 = clampi(s_iy[0], 0, a.in_h - 1), ys1 = clampi(s_iy[SR - 1] + 1, 0, a.in_h - 1);
         const int RW = xs1 - xs0 + 1, RH = ys1 - ys0 + 1;
         const bool staged = RW * RH <= IN_MAX;
-        if (staged) {
+        if (a.fast2x && staged) {
+            /* Exact 2x upscale (upscale_factor = +1, PopSift / VLFeat sampling: source coordinate = X / 2): the
+             * 1.8 fixed-point weights of the linear filter are exactly 0 or 1/2 (or 1 with the neighbour index, when the
+             * coordinate computes an ulp below an integer -- the same texel), so U is a copy / 2-point / 4-point
+             * average of the texels, formed in the generic path's operation order: (1-a) t0 + a t1 per row, then per
+             * column -- bit-identical, without the per-element coordinate arithmetic and the four LDS gathers.
+             * Columns and rows beyond the plane repeat its edge: U(X) = U(clamp X), as the clamped fetch gives. */
+            const int n = RW * RH;
+            if (MODE == 1) {
+                int b[IN_LD];
+#pragma unroll
+                for (int k = 0; k < IN_LD; k++) {
+                    const int i = tid + k * NT;
+                    if (i < n) {
+                        const int r = i / RW, c = i - r * RW;
+                        b[k] = ((const uint8_t*)a.in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < IN_LD; k++) {
+                    const int i = tid + k * NT;
+                    if (i < n) s_in[i] = s_lut[b[k]];
+                }
+            } else {
+                float b[IN_LD];
+#pragma unroll
+                for (int k = 0; k < IN_LD; k++) {
+                    const int i = tid + k * NT;
+                    if (i < n) {
+                        const int r = i / RW, c = i - r * RW;
+                        b[k] = ((const float*)a.in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < IN_LD; k++) {
+                    const int i = tid + k * NT;
+                    if (i < n) s_in[i] = b[k];
+                }
+            }
+            __syncthreads();
+            constexpr int CH = SW / 4; /* 16-byte chunks per LDS row; a chunk starts at an even X (tx0, HP multiples of 4) */
+            for (int idx = tid; idx < SR * CH; idx += NT) {
+                const int r = idx / CH, c4 = idx - r * CH;
+                const int Y = clampi(ty0 + r - HALO, 0, h - 1);
+                const int j0 = ((Y >> 1) - ys0) * RW, j1 = (min((Y >> 1) + 1, a.in_h - 1) - ys0) * RW;
+                const int X0 = tx0 + 4 * c4 - HP; /* even; X0 .. X0 + 3 */
+                /* source columns of U(clamp(X0 + q)): i = clamp(X) >> 1, and its right neighbour for odd X */
+                int   ia[4], ib[4];
+                bool  odd[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int X = clampi(X0 + q, 0, w - 1);
+                    ia[q] = (X >> 1) - xs0;
+                    ib[q] = min((X >> 1) + 1, a.in_w - 1) - xs0;
+                    odd[q] = (X & 1) != 0;
+                }
+                v4f out;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float t00 = s_in[j0 + ia[q]];
+                    float       top = t00;
+                    if (odd[q]) top = 0.5f * t00 + 0.5f * s_in[j0 + ib[q]];
+                    float val = top;
+                    if (Y & 1) {
+                        const float t01 = s_in[j1 + ia[q]];
+                        float       bot = t01;
+                        if (odd[q]) bot = 0.5f * t01 + 0.5f * s_in[j1 + ib[q]];
+                        val = 0.5f * top + 0.5f * bot;
+                    }
+                    out[q] = val;
+                }
+                reinterpret_cast<v4f*>(s_t)[idx] = out;
+            }
+        } else if (staged) {
             const int n = RW * RH;
             if (MODE == 1) {
                 int b[IN_LD];
@@ -347,6 +426,32 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
     }
 }
 
+template <int HALO, int MODE, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, TH>()];
+    blur_tile_body<HALO, MODE, TH, NT>(a, blockIdx.x, s_t);
+}
+
+/*
+ * Two level launches in one: workgroups [0, a.tiles) filter plane a, the rest plane b, both with the HALO-tap
+ * instance (a shorter filter runs with zero-padded taps, which does not change its results).  Used for the small
+ * octaves, whose launches are latency chains of a few microseconds each: levels L-2 and L-1 of octave o-1 do not
+ * depend on octave o, so they ride along with levels 1 and 2 of octave o (s_pyramid_build.cu:549-588 runs the
+ * octaves on separate streams for the same reason; one stream and merged launches do it here without the extra
+ * streams, which cost throughput when 16 contexts are in flight).
+ */
+template <int HALO>
+__global__ __launch_bounds__(256) void k_blur_duo(BlurArgs a, BlurArgs b)
+{
+    __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, 32>()];
+    const int na = a.tiles_x * a.tiles_y;
+    if ((int)blockIdx.x < na)
+        blur_tile_body<HALO, 0, 32, 256>(a, blockIdx.x, s_t);
+    else
+        blur_tile_body<HALO, 0, 32, 256>(b, blockIdx.x - na, s_t);
+}
+
 /* get_by_2_pick_every_second (s_pyramid_build.cu:50-71) */
 template <int MODE, int TH, int NT>
 hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
@@ -395,6 +500,31 @@ int blur_tile_h(int w, int h)
     constexpr long min_tiles = 512;
     const long tiles64 = (long)((w + TW - 1) / TW) * ((h + 63) / 64);
     return tiles64 >= min_tiles ? 64 : 32;
+}
+
+/* both planes with 32-row tiles and plane-to-plane filtering (mode 0) */
+hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, hipStream_t s)
+{
+    const int halo = std::max(span_a, span_b) - 1;
+    if (halo < 0 || halo > 30) return hipErrorInvalidValue;
+    const dim3 grid(a.tiles_x * a.tiles_y + b.tiles_x * b.tiles_y), block(256);
+#define PS_CASE(H)                                                      \
+    if (halo <= H) {                                                    \
+        hipLaunchKernelGGL((k_blur_duo<H>), grid, block, 0, s, a, b);   \
+        return hipGetLastError();                                       \
+    }
+    PS_CASE(4)
+    PS_CASE(5)
+    PS_CASE(6)
+    PS_CASE(7)
+    PS_CASE(8)
+    PS_CASE(10)
+    PS_CASE(13)
+    PS_CASE(16)
+    PS_CASE(22)
+    PS_CASE(30)
+#undef PS_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s)

@@ -3,7 +3,9 @@
  * (SURVEY 8(d) "T_e2e": wall time per image through enqueue() ... get() with many images in flight).
  * PCIe-inclusive: every image is uploaded and its features + descriptors (about 53 MB for the dense
  * synthetic 1080p image) are downloaded into a FeaturesHost.  Never the headline `value` of bench.py.
- *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--seed S]
+ *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--seed S] [--pgm a.pgm,b.pgm,...]
+ * --pgm: the images to cycle through (bench.py passes the popsift_amd/synth.py images of the headline workload);
+ * without it a cheap built-in generator is used.
  * Contexts per GPU come from POPSIFT_CONTEXTS_PER_DEVICE, GPUs from POPSIFT_DEVICES.
  */
 #include <popsift/features.h>
@@ -15,9 +17,13 @@
 #include <cstring>
 #include <deque>
 #include <random>
+#include <sstream>
+#include <string>
 #include <vector>
 
-/* a cheap stand-in for popsift_amd/synth.py: smoothed noise plus blobs, deterministic */
+#include "pgmread.h"
+
+/* built-in stand-in for popsift_amd/synth.py (used when no --pgm files are given): smoothed noise, deterministic */
 static std::vector<unsigned char> make_image(int w, int h, unsigned seed)
 {
     std::mt19937                          rng(seed);
@@ -48,15 +54,36 @@ int main(int argc, char** argv)
 {
     int images = 64, w = 1920, h = 1080, inflight = 16;
     unsigned seed = 1;
+    std::string pgm;
     for (int i = 1; i + 1 < argc; i += 2) {
-        if (!strcmp(argv[i], "--images")) images = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--pgm")) pgm = argv[i + 1];
+        else if (!strcmp(argv[i], "--images")) images = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--width")) w = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--height")) h = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--inflight")) inflight = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = (unsigned)atoi(argv[i + 1]);
     }
     std::vector<std::vector<unsigned char>> pool;
-    for (int k = 0; k < 4; k++) pool.push_back(make_image(w, h, seed + k));
+    if (!pgm.empty()) {
+        std::stringstream ss(pgm);
+        std::string       f;
+        while (std::getline(ss, f, ',')) {
+            int            pw = 0, ph = 0;
+            unsigned char* p = readPGMfile(f, pw, ph);
+            if (!p) return 2;
+            if (pool.empty()) {
+                w = pw;
+                h = ph;
+            } else if (pw != w || ph != h) {
+                fprintf(stderr, "popsift-bench: %s is not %d x %d\n", f.c_str(), w, h);
+                return 2;
+            }
+            pool.emplace_back(p, p + (size_t)pw * ph);
+            delete[] p;
+        }
+    }
+    if (pool.empty())
+        for (int k = 0; k < 4; k++) pool.push_back(make_image(w, h, seed + k));
 
     popsift::Config config;
     PopSift         sift(config, popsift::Config::ExtractingMode, PopSift::ByteImages);
@@ -87,9 +114,10 @@ int main(int argc, char** argv)
     run(images, f, d);
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("{\"e2e_host_api_mpix_s\": %.1f, \"images\": %d, \"width\": %d, \"height\": %d, \"contexts\": %d, "
-           "\"in_flight\": %d, \"ms_per_image\": %.3f, \"features_per_image\": %.0f, \"descriptors_per_image\": %.0f}\n",
+           "\"in_flight\": %d, \"ms_per_image\": %.3f, \"features_per_image\": %.0f, \"descriptors_per_image\": %.0f, "
+           "\"input\": \"%s\"}\n",
            (double)images * w * h / sec / 1e6, images, w, h, sift.getContextCount(), inflight, sec * 1e3 / images,
-           (double)f / images, (double)d / images);
+           (double)f / images, (double)d / images, pgm.empty() ? "built-in generator" : "pgm files");
     sift.uninit();
     return 0;
 }

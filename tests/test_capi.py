@@ -1,6 +1,7 @@
 """The C-ABI library loads on a machine without a GPU and exports every symbol that
 include/popsift_hip.h declares; no compute is attempted here."""
 import ctypes as C
+import subprocess
 import os
 import re
 
@@ -26,11 +27,31 @@ def test_header_symbols_are_exported_and_bound(hip):
     assert bound <= set(names), "bindings for undeclared symbols: %s" % (bound - set(names))
 
 
-def test_struct_layouts_match_the_header(hip):
-    assert C.sizeof(hip.Params) == 20 * 4
+def test_struct_layouts_match_the_header(hip, tmp_path):
+    """sizeof / offsetof as a C compiler sees include/popsift_hip.h against the ctypes mirrors of the binding."""
+    src = tmp_path / "layout.c"
+    src.write_text(r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "popsift_hip.h"
+int main(void)
+{
+    printf("%zu %zu %zu %zu %zu %zu\n", sizeof(popsift_hip_params), sizeof(popsift_hip_feature), sizeof(popsift_hip_extremum),
+           sizeof(popsift_hip_report), sizeof(popsift_hip_match), sizeof(popsift_hip_device_info));
+    printf("%zu %zu %zu %zu %zu\n", offsetof(popsift_hip_params, store_dog), offsetof(popsift_hip_report, ms_device),
+           offsetof(popsift_hip_report, pyramid_pixels), offsetof(popsift_hip_report, ms_stage),
+           offsetof(popsift_hip_feature, desc_idx));
+    return 0;
+}
+""")
+    exe = str(tmp_path / "layout.bin")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    sizes, offs = [list(map(int, l.split())) for l in subprocess.check_output([exe], text=True).splitlines()]
+    assert sizes == [C.sizeof(hip.Params), hip.FEATURE_DTYPE.itemsize, hip.EXTREMUM_DTYPE.itemsize, C.sizeof(hip.Report),
+                     hip.MATCH_DTYPE.itemsize, C.sizeof(hip.DeviceInfo)]
+    assert offs == [hip.Params.store_dog.offset, hip.Report.ms_device.offset, hip.Report.pyramid_pixels.offset,
+                    hip.Report.ms_stage.offset, hip.FEATURE_DTYPE.fields["desc_idx"][1]]
     assert hip.FEATURE_DTYPE.itemsize == 52          # 5 scalars + 4 angles + 4 indices
-    assert hip.EXTREMUM_DTYPE.itemsize == 24
-    assert C.sizeof(hip.Report) == (3 + 20 + 20 + 2) * 4 + 3 * 4 + 2 * 8 + 8 + 4 + 4
 
 
 def test_default_params_are_the_reference_defaults(hip):

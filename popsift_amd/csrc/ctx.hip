@@ -27,6 +27,7 @@
 #include "devfeatures.h"
 #include "kernels.h"
 #include "sift_types.h"
+#include "trace.h"
 
 using namespace popsift_hip;
 
@@ -131,6 +132,24 @@ int fail(popsift_hip_ctx* c, int code, const char* fmt, ...)
             return fail((c), e__ == hipErrorOutOfMemory ? POPSIFT_HIP_ERR_OOM : POPSIFT_HIP_ERR_DEVICE, \
                         "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__));          \
     } while (0)
+
+/* POP_SYNC_CHK (common/debug_macros.h:25-29): in a SYNC_CHECK build every launch of the per-image sequence is followed
+ * by a stream synchronisation and an error check, so a faulting kernel is named where it was launched */
+#ifdef POPSIFT_SYNC_CHECK
+#define SYNC_CHK(c, what)                                                                                     \
+    do {                                                                                                      \
+        hipError_t e__ = hipStreamSynchronize((c)->stream);                                                   \
+        if (e__ == hipSuccess) e__ = hipGetLastError();                                                       \
+        if (e__ != hipSuccess) {                                                                              \
+            fprintf(stderr, "%s:%d sync check after %s: %s\n", __FILE__, __LINE__, what, hipGetErrorString(e__)); \
+            return fail((c), POPSIFT_HIP_ERR_DEVICE, "sync check after %s: %s", what, hipGetErrorString(e__)); \
+        }                                                                                                     \
+    } while (0)
+#else
+#define SYNC_CHK(c, what) \
+    do {                  \
+    } while (0)
+#endif
 
 /* GaussInfo::getSpan, gauss_filter.cu:274-328 */
 int span_for(int gauss_mode, float sigma)
@@ -387,6 +406,7 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int t
         HIP_TRY(c, hipEventRecord(ep.b, c->stream));
     } else {
         HIP_TRY(c, launch_blur(a, mode, span, tile_h, c->stream));
+        SYNC_CHK(c, "k_blur_tile");
     }
     return 0;
 }
@@ -424,6 +444,7 @@ BlurArgs level_args(const popsift_hip_ctx* c, int o, int level)
  */
 int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch)
 {
+    POPSIFT_RANGE("popsift_hip: pyramid");
     const PyrDesc& pd = c->pd;
     const int      L = pd.L;
     auto single = [&](int o, int level) -> int {
@@ -468,6 +489,7 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
             if (pair && level <= 2) {
                 const BlurArgs a = level_args(c, o, level), b = level_args(c, o - 1, trail);
                 HIP_TRY(c, launch_blur_duo(a, c->tab.span[level], b, c->tab.span[trail], c->stream));
+                SYNC_CHK(c, "k_blur_duo");
             } else {
                 if (int rc = single(o, level)) return rc;
                 if (!pair && level <= 2 && o >= 2)
@@ -486,26 +508,32 @@ InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iex
 
 int enqueue_keypoint_stages(popsift_hip_ctx* c)
 {
+    POPSIFT_RANGE("popsift_hip: keypoint stages");
     const bool stages = (c->profile == 2);
     auto       mark = [&](int k) -> hipError_t { return stages ? hipEventRecord(c->ev_stage[k], c->stream) : hipSuccess; };
     HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DETECT)); /* = end of the pyramid stage */
     HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_ovf, c->d_iext,
                               c->stream, stages ? c->ev_stage[POPSIFT_HIP_STAGE_REFINE] : nullptr));
+    SYNC_CHK(c, "k_detect / k_refine");
     if (c->sc.filter_max > 0) {
         /* Pyramid::orientation's filter hook (s_orientation.cu:353-367); the 10 % test is taken on the device */
         HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->d_ct, c->d_iext, c->d_iext2, c->d_fstate, c->d_fhist, c->stream));
+        SYNC_CHK(c, "grid filter");
     }
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_ORIENTATION));
     HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->kp_waves,
                                   c->stream));
+    SYNC_CHK(c, "k_orientation");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_SCAN));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->d_ext, c->d_partial,
                            std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_feats, c->desc_cap, c->stream));
+    SYNC_CHK(c, "k_scan_local / k_scan_apply");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DESCRIPTOR));
     HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->kp_waves,
                                   c->stream));
+    SYNC_CHK(c, "descriptor kernel");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_COUNT));
     HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     return 0;
@@ -514,6 +542,7 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c)
 int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32, int w, int h, int pitch)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
+    POPSIFT_RANGE("popsift_hip: submit");
     if (!img || w <= 0 || h <= 0 || pitch < w) return fail(c, POPSIFT_HIP_ERR_INVALID, "bad image arguments");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->have_image && !c->finished) {
@@ -563,6 +592,7 @@ int finish(popsift_hip_ctx* c)
 {
     if (!c->have_image) return fail(c, POPSIFT_HIP_ERR_STATE, "no image submitted");
     if (c->finished) return 0;
+    POPSIFT_RANGE("popsift_hip: wait");
     HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -873,6 +903,7 @@ int popsift_hip_fetch(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t fea
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
     if (int rc = finish(c)) return rc;
+    POPSIFT_RANGE("popsift_hip: fetch");
     const size_t nf = (size_t)c->rep.ext_total, nd = (size_t)c->rep.ori_total;
     if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
     if (feats_cap < nf || desc_cap < nd * 128) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");

@@ -24,6 +24,7 @@
 #include "debug_dump.h"
 #include "popsift/common/device_prop.h"
 #include "popsift_hip.h"
+#include "../csrc/trace.h" /* POPSIFT_RANGE: roctx ranges in a ROCTX=1 build (the reference: NVTX, popsift.h:20-25) */
 
 using namespace std;
 
@@ -231,6 +232,7 @@ void PopSift::worker_loop(Worker* me)
             if (job == 0) return; /* shutdown marker stays for the other workers */
             _queue.pop();
         }
+        POPSIFT_RANGE("PopSift job (submit, wait, fetch)");
         int rc;
         if (job->isFloat())
             rc = popsift_hip_submit_f32(me->ctx, (const float*)job->getImageData(), job->getWidth(), job->getHeight(),

@@ -75,16 +75,18 @@ def assert_keypoints_match(orc, ctx, grid_mode=False):
     assert st["max_sigma_rel"] < 1e-5
     n = max(st["n_desc"], 1)
     assert st["num_ori_diff"] <= max(1, st["n_a"] // 2000)
-    assert st["ang_bad"] <= max(1, n // 500), st
+    assert st["ang_bad"] <= max(2, n // 2000), st
     if grid_mode:
         # DescMode Grid snaps each of its 4096 sample points per descriptor to the nearest pixel
-        # (s_desc_grid.cu:77): an ulp of difference in sin/cos (device vs host libm; the reference's
-        # own __sincosf is far coarser) moves a point across a .5 boundary in a few percent of the
-        # descriptors and swaps one of the 256 samples of a cell.  Most stay within 1e-3.
-        assert st["desc_bad"] <= n // 15, st
+        # (s_desc_grid.cu:77): an ulp of difference in the orientation moves a point across a .5 boundary
+        # in about one descriptor in a hundred and swaps one of the 256 samples of a cell (measured 98.9 % within
+        # 1e-3 over 51 206 descriptors, tools/grid_stat.py).  Bar: >= 98 %.
+        assert st["desc_bad"] <= max(3, n // 50), st
         assert st["max_desc"] < 6e-2 and st["max_ang"] < 3e-2, st
     else:
-        assert st["desc_bad"] <= max(1, n // 500), st
+        # loop / iloop / notile / igrid: measured 99.996 % within 1e-3 over 510 145 descriptors (tools/parity_stat.py);
+        # bar >= 99.98 % (two descriptors on the small images of this suite)
+        assert st["desc_bad"] <= max(2, -(-n // 5000)), st
         assert st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2, st
     # layout contract of the reference: descriptors feature by feature, octaves ascending
     idx = np.concatenate([f["desc_idx"][: int(f["num_ori"])] for f in fh]) if len(fh) else np.zeros(0, int)

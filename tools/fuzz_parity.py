@@ -1,69 +1,25 @@
-"""Randomised differential test: oracle vs HIP on random sizes / parameters (planes and extrema bit-exact,
-descriptors by tolerance).  Not part of the pytest suite (minutes of oracle time); run on the GPU box."""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+"""Randomised differential test: oracle vs HIP on random sizes / parameters (tests/fuzz_cases.py; a fixed 60-case
+slice of it is tests/test_gpu_fuzz.py).  Open-ended here: python3 tools/fuzz_parity.py [n_cases] [seed], on the GPU box."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from popsift_amd import _capi as hip
-from popsift_amd.synth import synth
+
+import fuzz_cases
 from oracle import oracle as O
-from util import bits, compare_features
+from popsift_amd import _capi as hip
 
 O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 for case in range(n_cases):
-    w = int(rng.integers(9, 700)); h = int(rng.integers(9, 500))
-    kw = dict(levels=int(rng.integers(2, 7)), sigma=float(np.float32(rng.uniform(1.0, 2.0))),
-              sift_mode=int(rng.integers(0, 3)), gauss_mode=int(rng.choice([0, 3])),
-              upscale_factor=float(rng.choice([1.0, 1.0, 0.0, -1.0])), norm_mode=int(rng.integers(0, 2)),
-              norm_multi=int(rng.choice([0, 0, 9])), desc_mode=int(rng.choice([0, 0, 0, 2, 4])),
-              edge_limit=float(np.float32(rng.uniform(5, 15))), threshold=float(np.float32(rng.uniform(0.02, 0.08))),
-              max_extrema=int(rng.choice([100000, 100000, 300])))
-    if rng.random() < 0.3:
-        kw["octaves"] = int(rng.integers(1, 6))
-    if rng.random() < 0.25 and kw["max_extrema"] != 300:   # a binding cap keeps an arrival-order subset: not comparable
-        kw.update(filter_max_extrema=int(rng.integers(50, 600)), filter_sorting=int(rng.integers(1, 3)),
-                  filter_grid_size=int(rng.integers(1, 6)))
-    img = synth(1000 + case, w, h)
-    if rng.random() < 0.3:
-        img = (img.astype(np.float32) / 256.0)
-    t0 = time.time()
-    try:
-        orc = O.Oracle(O.default_params(**kw), threads=16).run(img)
-        ctx = hip.Context(hip.default_params(**kw)); ctx.submit(img); ctx.wait()
-        ok = ctx.report().num_octaves == orc.num_octaves
-        L = max(2, kw["levels"]) + 3
-        for o in range(orc.num_octaves):
-            for l in range(L):
-                ok = ok and np.array_equal(bits(orc.plane(o, 0, l)), bits(ctx.plane(o, 0, l)))
-            for l in range(L - 1):
-                ok = ok and np.array_equal(bits(orc.plane(o, 1, l)), bits(ctx.plane(o, 1, l)))
-        planes_ok = ok
-        capped = kw["max_extrema"] == 300 and max(orc.ext_counts() + [0]) >= 300
-        msg = ""
-        if not capped:  # with a binding max_extrema cap the surviving subset depends on arrival order
-            eo, eh = orc.extrema(), ctx.extrema()
-            key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
-            ext_ok = key(eo) == key(eh)
-            ok = ok and ext_ok
-            if ext_ok:
-                st = compare_features(*orc.fetch(), *ctx.fetch())
-                n = max(st["n_desc"], 1)
-                # grid snaps its sample points to pixels: a few percent of descriptors differ by up to 1e-1
-                lim = max(3, n // 5) if kw["desc_mode"] == 2 else max(2, n // 300)
-                dok = st["missing"] == 0 and st["desc_bad"] <= lim and st["max_sigma_rel"] < 1e-5 and st["max_desc"] < 1e-1
-                ok = ok and dok
-                msg = "desc_bad %d/%d max %.1e" % (st["desc_bad"], n, st["max_desc"])
-            else:
-                msg = "EXTREMA DIFFER %d vs %d" % (len(eo), len(eh))
-        else:
-            msg = "capped"
-        ctx.close()
-    except Exception as e:
-        ok, planes_ok, msg = False, False, "EXCEPTION %r" % (e,)
+    kw, img = fuzz_cases.random_case(rng, case)
+    ok, msg = fuzz_cases.check_case(O, hip, kw, img)
     bad += 0 if ok else 1
-    print("%s case %2d %dx%d %s planes %s %s  (%.1fs)" % ("ok  " if ok else "FAIL", case, w, h, kw, planes_ok, msg, time.time() - t0), flush=True)
+    print("%s case %2d %dx%d %s %s" % ("ok  " if ok else "FAIL", case, img.shape[1], img.shape[0], kw, msg), flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)

@@ -80,6 +80,14 @@ public:
 
 typedef FeaturesHost Features;
 
+/* Extensions: the result arrays of FeaturesHost are pinned blocks from a process-wide pool; free blocks are cached for
+ * reuse (POPSIFT_PINNED_CACHE_MB, default 2048) and released when the last PopSift object of the process is shut down.
+ * releasePinnedCache() releases them at once; pinnedCacheBytes() tells how much is cached. */
+void   releasePinnedCache();
+size_t pinnedCacheBytes();
+/* the NUMA node (or -1) whose free list serves the calling thread's result blocks; PopSift's workers set it */
+void   setPinnedPoolNode(int node);
+
 std::ostream& operator<<(std::ostream& ostr, const FeaturesHost& feature);
 
 /*

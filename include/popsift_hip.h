@@ -155,6 +155,11 @@ typedef struct popsift_hip_device_info {
     int32_t  unified_addressing;
 } popsift_hip_device_info;
 int popsift_hip_get_device_info(int device, popsift_hip_device_info* out);
+/* NUMA node the GPU hangs off (from its PCI address, /sys/bus/pci/devices/<id>/numa_node), -1 when the host does not
+ * say.  The C++ layer binds each worker thread to that node's CPUs, so that the staging copy of the image and the
+ * pinned result blocks the worker allocates are node-local; no counterpart in the single-GPU
+ * reference. */
+int popsift_hip_device_numa_node(int device, int* node);
 
 /* Replaces PopSift::configure (popsift.cpp:63-87: init_filter + init_constants)
  * and Pyramid::Pyramid (sift_pyramid.cu:108-165); buffers are sized lazily on

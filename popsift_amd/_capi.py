@@ -84,6 +84,7 @@ SYMBOLS = [
     ("popsift_hip_last_error", C.c_char_p, [_vp]),
     ("popsift_hip_device_count", C.c_int, [_ip]),
     ("popsift_hip_get_device_info", C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),
+    ("popsift_hip_device_numa_node", C.c_int, [C.c_int, _ip]),
     ("popsift_hip_ctx_create", C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(_vp)]),
     ("popsift_hip_ctx_destroy", C.c_int, [_vp]),
     ("popsift_hip_get_gauss_table", C.c_int, [_vp, _vp, _vp, _vp, _ip]),

@@ -765,6 +765,27 @@ int popsift_hip_get_device_info(int device, popsift_hip_device_info* out)
     return POPSIFT_HIP_OK;
 }
 
+int popsift_hip_device_numa_node(int device, int* node)
+{
+    if (!node) return POPSIFT_HIP_ERR_INVALID;
+    *node = -1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return POPSIFT_HIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return POPSIFT_HIP_ERR_INVALID;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return POPSIFT_HIP_ERR_DEVICE;
+    for (char* q = bus; *q; q++)
+        if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a'); /* sysfs spells the address in lower case */
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    if (FILE* f = fopen(path, "r")) {
+        int v = -1;
+        if (fscanf(f, "%d", &v) == 1) *node = v;
+        fclose(f);
+    }
+    return POPSIFT_HIP_OK;
+}
+
 int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_ctx** out)
 {
     if (!p || !out) return POPSIFT_HIP_ERR_INVALID;

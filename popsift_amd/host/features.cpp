@@ -18,37 +18,40 @@ namespace popsift {
 namespace {
 
 /*
- * Result buffers come from a process-wide pool of pinned host blocks (power-of-two size classes):
- * the device-to-host copy of a job then runs at PCIe speed straight into the memory the caller
- * sees.  The reference pins and unpins the freshly allocated arrays around every download
- * (cudaHostRegister, features.cu:84-109), which costs milliseconds per image.  When pinned
+ * Result buffers come from a process-wide pool of pinned host blocks: the device-to-host copy of a job then runs at
+ * PCIe speed straight into the memory the caller sees.  The reference pins and unpins the freshly allocated arrays
+ * around every download (cudaHostRegister, features.cu:84-109), which costs milliseconds per image.  When pinned
  * memory cannot be had (no GPU runtime), blocks are plain page-aligned allocations.
+ *   - size classes grow by a quarter (a 70 MB result takes an 82 MB block, not a 128 MB power of two);
+ *   - blocks are allocated and released OUTSIDE the pool lock (pinning tens of MB takes tens of milliseconds);
+ *   - at most POPSIFT_PINNED_CACHE_MB (default 2 GiB) of free blocks are kept, and none once the last PopSift object
+ *     of the process has been shut down (trim(), called from PopSift::uninit): a long-running host application does
+ *     not keep gigabytes of unswappable memory after it is done extracting.
  */
 class BlockPool {
     struct Block {
         void*  p;
         size_t cap;
         bool   pinned;
+        int    node; /* NUMA node of the thread that allocated (first touched) it, -1 unknown */
     };
-    std::mutex                   _m;
-    std::multimap<size_t, Block> _free; /* by capacity */
+    typedef std::pair<int, size_t> Key; /* (node, capacity): a worker reuses blocks of its own node only */
+    std::mutex                _m;
+    std::multimap<Key, Block> _free;
     std::map<void*, Block>       _live;
-    /* bytes kept for reuse (POPSIFT_PINNED_CACHE_MB, default 8 GiB): a 1080p result is ~70 MB and every job in
-     * flight holds one, so a small cache makes workers allocate and free pinned memory per image -- calls that
-     * stall the GPU queues of ALL contexts */
     const size_t                 MAX_CACHED = cache_limit();
     size_t                       _cached = 0;
 
     static size_t cache_limit()
     {
         const char* e = getenv("POPSIFT_PINNED_CACHE_MB");
-        const long  mb = e ? atol(e) : 8192;
+        const long  mb = e ? atol(e) : 2048;
         return (size_t)(mb < 0 ? 0 : mb) << 20;
     }
     static size_t round_up(size_t n)
     {
         size_t c = 4096;
-        while (c < n) c <<= 1;
+        while (c < n) c = (c + c / 4 + 4095) & ~(size_t)4095;
         return c;
     }
     static void release(const Block& b)
@@ -58,40 +61,62 @@ class BlockPool {
     }
 
 public:
-    void* get(size_t bytes)
+    void* get(size_t bytes, int node)
     {
-        const size_t                cap = round_up(bytes);
-        std::lock_guard<std::mutex> lk(_m);
-        auto                        it = _free.lower_bound(cap);
-        if (it != _free.end() && it->first <= 2 * cap) {
-            Block b = it->second;
-            _free.erase(it);
-            _cached -= b.cap;
-            _live[b.p] = b;
-            return b.p;
+        const size_t cap = round_up(bytes);
+        {
+            std::lock_guard<std::mutex> lk(_m);
+            auto                        it = _free.lower_bound(Key(node, cap));
+            if (it != _free.end() && it->first.first == node && it->first.second <= cap + cap / 2) {
+                Block b = it->second;
+                _free.erase(it);
+                _cached -= b.cap;
+                _live[b.p] = b;
+                return b.p;
+            }
         }
-        Block b{popsift_hip_host_alloc(cap), cap, true};
+        Block b{popsift_hip_host_alloc(cap), cap, true, node}; /* not under the lock: other workers keep going */
         if (!b.p) {
             b.pinned = false;
             if (posix_memalign(&b.p, (size_t)sysconf(_SC_PAGESIZE), cap) != 0) return 0;
         }
+        std::lock_guard<std::mutex> lk(_m);
         _live[b.p] = b;
         return b.p;
     }
     void put(void* p)
     {
         if (!p) return;
-        std::lock_guard<std::mutex> lk(_m);
-        auto                        it = _live.find(p);
-        if (it == _live.end()) return;
-        Block b = it->second;
-        _live.erase(it);
-        if (_cached + b.cap > MAX_CACHED) {
-            release(b);
-        } else {
-            _cached += b.cap;
-            _free.insert(std::make_pair(b.cap, b));
+        Block b;
+        {
+            std::lock_guard<std::mutex> lk(_m);
+            auto                        it = _live.find(p);
+            if (it == _live.end()) return;
+            b = it->second;
+            _live.erase(it);
+            if (_cached + b.cap <= MAX_CACHED) {
+                _cached += b.cap;
+                _free.insert(std::make_pair(Key(b.node, b.cap), b));
+                return;
+            }
         }
+        release(b);
+    }
+    /* give every cached block back to the system (blocks held by live results are untouched) */
+    void trim()
+    {
+        std::multimap<Key, Block> drop;
+        {
+            std::lock_guard<std::mutex> lk(_m);
+            drop.swap(_free);
+            _cached = 0;
+        }
+        for (auto& kv : drop) release(kv.second);
+    }
+    size_t cached_bytes()
+    {
+        std::lock_guard<std::mutex> lk(_m);
+        return _cached;
     }
 };
 
@@ -102,6 +127,12 @@ BlockPool& pool()
 }
 
 }  // namespace
+
+thread_local int t_pool_node = -1;
+
+void   setPinnedPoolNode(int node) { t_pool_node = node; }
+void   releasePinnedCache() { pool().trim(); }
+size_t pinnedCacheBytes() { return pool().cached_bytes(); }
 
 FeaturesHost::FeaturesHost() : _ext(0), _ori(0) {}
 
@@ -118,13 +149,13 @@ void FeaturesHost::reset(int num_ext, int num_ori)
     pool().put(_ext);
     pool().put(_ori);
     /* page-aligned like the reference (features.cu:63,72); zero-sized results stay valid objects */
-    _ext = (Feature*)pool().get(std::max<size_t>((size_t)num_ext * sizeof(Feature), 1));
+    _ext = (Feature*)pool().get(std::max<size_t>((size_t)num_ext * sizeof(Feature), 1), t_pool_node);
     if (_ext == 0) {
         std::cerr << __FILE__ << ":" << __LINE__ << " Runtime error:" << std::endl
                   << "    Failed to (re)allocate memory for downloading " << num_ext << " features" << std::endl;
         exit(-1);
     }
-    _ori = (Descriptor*)pool().get(std::max<size_t>((size_t)num_ori * sizeof(Descriptor), 1));
+    _ori = (Descriptor*)pool().get(std::max<size_t>((size_t)num_ori * sizeof(Descriptor), 1), t_pool_node);
     if (_ori == 0) {
         std::cerr << __FILE__ << ":" << __LINE__ << " Runtime error:" << std::endl
                   << "    Failed to (re)allocate memory for downloading " << num_ori << " descriptors" << std::endl;

@@ -13,6 +13,7 @@
 #include "popsift/popsift.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,9 @@
 #include <iostream>
 #include <sstream>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "debug_dump.h"
 #include "popsift/common/device_prop.h"
@@ -125,6 +129,38 @@ void print_gauss_tables(const popsift::Config& conf, popsift_hip_ctx* ctx)
     fflush(stdout);
 }
 
+std::atomic<int> g_live_pipelines{0}; /* PopSift objects with running workers */
+
+/* Bind the calling worker thread to the CPUs of the NUMA node its GPU hangs off (one host thread per
+ * context, NUMA-local pinned buffers): the image staging copy and every pinned block the worker allocates afterwards
+ * are then first touched on that node.  Quietly does nothing where the host does not expose the topology. */
+void bind_to_numa_node(int node)
+{
+    if (node < 0) return;
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    char list[4096] = {0};
+    const bool ok = fgets(list, sizeof(list), f) != 0;
+    fclose(f);
+    if (!ok) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(0, ",\n")) { /* "0-15,128-143" */
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1) b = a;
+        if (k < 1) continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) {
+            CPU_SET(c, &set);
+            n++;
+        }
+    }
+    if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+
 int contexts_per_device()
 {
     const char* e = getenv("POPSIFT_CONTEXTS_PER_DEVICE");
@@ -219,10 +255,16 @@ void PopSift::start_workers(int w, int h)
     if (_config.ifPrintGaussTables() && !_workers.empty()) print_gauss_tables(_config, _workers[0]->ctx);
     for (Worker* wk : _workers) wk->thread = std::thread(&PopSift::worker_loop, this, wk);
     _started = true;
+    g_live_pipelines++;
 }
 
 void PopSift::worker_loop(Worker* me)
 {
+    {
+        int node = -1;
+        if (popsift_hip_device_numa_node(me->device, &node) == POPSIFT_HIP_OK) bind_to_numa_node(node);
+        popsift::setPinnedPoolNode(node); /* result blocks this thread takes come from / go to its node's free list */
+    }
     for (;;) {
         SiftJob* job;
         {
@@ -309,7 +351,10 @@ void PopSift::uninit()
         popsift_hip_host_free(wk->pod);
         delete wk;
     }
+    const bool had_workers = !_workers.empty();
     _workers.clear();
+    /* the last pipeline of the process is gone: give the cached pinned result blocks back (features.cpp) */
+    if (had_workers && --g_live_pipelines == 0) popsift::releasePinnedCache();
 }
 
 SiftJob* PopSift::enqueue(int w, int h, const unsigned char* imageData)

@@ -75,6 +75,17 @@ int main()
     CHECK(line.rfind("10.5 20.25 0.25 0 0.25 0.125 ", 0) == 0);   // x y 1/s^2 0 1/s^2 d0 ...
     popsift::FeaturesHost empty(0, 0);
     CHECK(empty.size() == 0 && empty.begin() == empty.end());
+    // result blocks come from a pool: a freed result is cached for reuse, releasePinnedCache() returns it to the system
+    {
+        popsift::FeaturesHost* big = new popsift::FeaturesHost(1000, 3000);
+        popsift::Descriptor*   where = big->getDescriptors();
+        delete big;
+        CHECK(popsift::pinnedCacheBytes() >= 3000 * sizeof(popsift::Descriptor));
+        popsift::FeaturesHost again(900, 2900);          // a little smaller: same size class, same block
+        CHECK(again.getDescriptors() == where);
+    }
+    popsift::releasePinnedCache();
+    CHECK(popsift::pinnedCacheBytes() == 0);
 
     // a PopSift object can be made and torn down without ever touching a GPU
     {

@@ -90,7 +90,9 @@ int main()
     delete j0;
     delete j1;
     a.uninit();
+    CHECK(popsift::pinnedCacheBytes() > 0); /* b still runs: the pool keeps its free blocks */
     b.uninit();
+    CHECK(popsift::pinnedCacheBytes() == 0); /* the last pipeline is gone: no pinned memory stays behind */
     std::printf("host_mt_test ok\n");
     return 0;
 }

@@ -1,4 +1,10 @@
-"""Turns gpurun_out/profiles_raw (tools/collect_profiles.sh) into the committed summaries in profiles/."""
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh into the summaries committed under profiles/:
+  <tag>_bench_kernel_stats.txt         kernel stats of the profiled bench run + its JSON line
+  <tag>_single_image_kernel_stats.txt  kernel stats and the per-launch timeline of one context extracting 5 images
+  <tag>_kernel_counters.txt            every counter, per kernel and per image
+  <tag>_kernel_counters.json           per pipeline stage: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 note of
+                                       MI355X_MICROARCH.md 'HBM') and vector instructions per image -- what bench.py quotes
+usage: summarize_profiles.py <tag> <raw dir> <out dir> <images per counter pass>"""
 import collections
 import csv
 import glob
@@ -6,14 +12,13 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
-OUT = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG, RAW, OUT, NIMG = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+STAGES = (("pyramid", ("k_blur_tile", "k_blur_duo")), ("detect", ("k_detect",)), ("refine", ("k_refine", "k_filter")),
+          ("orientation", ("k_orientation",)), ("scan", ("k_scan_",)), ("descriptor", ("k_descriptor",)))
 
 
 def short(n):
-    return n.replace("popsift_hip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return n.replace("popsift_hip::(anonymous namespace)::", "").replace("popsift_hip::", "").replace("void ", "").split("(")[0]
 
 
 def stats(sub):
@@ -23,7 +28,7 @@ def stats(sub):
     for r in rows:
         lines.append("%-44s %7s %12.1f %11.2f %8s" % (short(r["Name"])[:44], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
                                                      float(r["AverageNs"]) / 1e3, r["Percentage"][:6]))
-    return rows, "\n".join(lines)
+    return "\n".join(lines)
 
 
 def timeline(sub, nimg):
@@ -43,54 +48,51 @@ def timeline(sub, nimg):
     return "\n".join(out)
 
 
-def pmc(sub, counter, nimg):
-    f = sorted(glob.glob(os.path.join(RAW, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1]
+def counters(sub):
+    """kernel -> counter -> sum over all dispatches of the pass"""
+    fs = glob.glob(os.path.join(RAW, sub, "**", "*counter_collection.csv"), recursive=True)
     agg = collections.OrderedDict()
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
-        k = agg.setdefault(short(r["Kernel_Name"]), [0.0, 0])
-        k[0] += float(r["Counter_Value"])
-        k[1] += 1
+    if not fs:
+        return agg
+    for r in csv.DictReader(open(sorted(fs, key=os.path.getmtime)[-1])):
+        k = agg.setdefault(short(r["Kernel_Name"]), collections.OrderedDict())
+        k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     return agg
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    _, txt = stats("bench")
     bench_line = [l for l in open(os.path.join(RAW, "bench.log")).read().splitlines() if l.startswith('{"metric"')][-1]
     open(os.path.join(OUT, "%s_bench_kernel_stats.txt" % TAG), "w").write(
         "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline\n"
-        "# (16 contexts in flight, 1 MI355X; includes warm-up, the latency and the profile-mode passes)\n"
-        + txt + "\n\n# bench.py output of this profiled run:\n" + bench_line + "\n")
-    _, txt = stats("roofline")
-    rl = [l for l in open(os.path.join(RAW, "roofline.log")).read().splitlines() if l.startswith('{"metric"')][-1]
-    open(os.path.join(OUT, "%s_roofline_pass_kernel_stats.txt" % TAG), "w").write(
-        "# rocprofv3 --kernel-trace --stats -- python3 bench.py --only-roofline\n"
-        "# (one context: 1 timed image, 5 latency images, 5 profile-mode images in which every blur launch\n"
-        "#  is issued 4x back to back between one HIP event pair; compare roofline.avg_launch_us below with the\n"
-        "#  avg_us of the k_blur_tile<*, 0, 64, *> rows)\n" + txt + "\n\n# bench.py --only-roofline output:\n" + rl + "\n")
-    rows, txt = stats("single")
+        "# (16 contexts in flight, 1 MI355X; includes warm-up and the single-image / profile-mode / sparse / host-to-host legs)\n"
+        + stats("bench") + "\n\n# bench.py output of this profiled run:\n" + bench_line + "\n")
     open(os.path.join(OUT, "%s_single_image_kernel_stats.txt" % TAG), "w").write(
-        "# rocprofv3 --kernel-trace --stats -- python3 tools/prof_run.py 5   (one context, 5 x config-2 image)\n" + txt +
+        "# rocprofv3 --kernel-trace --stats -- python3 tools/prof_run.py 5   (one context, 5 x config-2 image)\n" + stats("single") +
         "\n\n# per-launch timeline of the last image\n" + timeline("single", 5) + "\n")
-    fetch, write = pmc("pmc_fetch", "FETCH_SIZE", 3), pmc("pmc_write", "WRITE_SIZE", 3)
-    lines = ["# HBM-side traffic per launch from rocprofv3 PMC passes (separate runs for FETCH_SIZE and WRITE_SIZE).",
-             "# Units: KiB as reported; bytes = KiB * 1024; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request,",
-             "# MI355X_MICROARCH.md 'HBM').  3 images per run; values are averages per launch.",
-             "%-36s %9s %14s %14s %14s" % ("kernel", "launches", "fetch_MB(x2)", "write_MB", "traffic_MB")]
-    traffic = {}
-    for k in fetch:
-        n = fetch[k][1]
-        fb = 2.0 * fetch[k][0] / n * 1024 / 1e6
-        wb = write.get(k, [0, 1])[0] / max(write.get(k, [0, 1])[1], 1) * 1024 / 1e6
-        traffic[k] = {"launches": n, "fetch_bytes": fb * 1e6, "write_bytes": wb * 1e6, "traffic_bytes": (fb + wb) * 1e6}
-        lines.append("%-36s %9d %14.2f %14.2f %14.2f" % (k[:36], n, fb, wb, fb + wb))
-    open(os.path.join(OUT, "%s_hbm_traffic.txt" % TAG), "w").write("\n".join(lines) + "\n")
-    big = [v for k, v in traffic.items() if k.startswith("k_blur_tile<") and ", 0, 64" in k]
-    if big:
-        per_launch = sum(v["traffic_bytes"] * v["launches"] for v in big) / sum(v["launches"] for v in big)
-        json.dump({"kernel": "k_blur_tile<HALO,0,64,*>", "config": "1920x1080 u8, default Config (octave 0 level launches)",
-                   "traffic_bytes_per_launch": per_launch, "source": "%s_hbm_traffic.txt" % TAG},
-                  open(os.path.join(OUT, "blur_traffic.json"), "w"), indent=1)
-    print(open(os.path.join(OUT, "%s_hbm_traffic.txt" % TAG)).read())
+    allc = collections.OrderedDict()
+    for sub in ("sq_inst", "sq_wait", "sq_lds", "tcc", "grbm", "fetch", "write"):
+        for k, v in counters(sub).items():
+            allc.setdefault(k, collections.OrderedDict()).update(v)
+    names = []
+    for v in allc.values():
+        for c in v:
+            if c not in names:
+                names.append(c)
+    lines = ["# rocprofv3 --pmc <group> --kernel-trace -- python3 tools/prof_run.py %d: one pass per counter group (tools/collect_profiles.sh)." % NIMG,
+             "# Values are PER IMAGE (sum over the kernel's dispatches of the pass / %d images).  FETCH_SIZE / WRITE_SIZE in KiB as" % NIMG,
+             "# reported; hbm_MB = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / 1e6 (gfx950 counts half of a wide read, MI355X_MICROARCH.md).",
+             "# SQ_*_CYCLES count quad-cycles.", "%-34s" % "kernel" + " ".join("%14s" % n[-14:] for n in names) + "%12s" % "hbm_MB"]
+    stage = collections.OrderedDict((s, {"hbm_bytes": 0.0, "valu_insts": 0.0, "kernels": []}) for s, _ in STAGES)
+    for k, v in allc.items():
+        hbm = (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / NIMG
+        lines.append("%-34s" % k[:34] + " ".join("%14.5g" % (v.get(n, 0.0) / NIMG) for n in names) + "%12.2f" % (hbm / 1e6))
+        for s, pre in STAGES:
+            if k.startswith(pre):
+                stage[s]["hbm_bytes"] += hbm
+                stage[s]["valu_insts"] += v.get("SQ_INSTS_VALU", 0.0) / NIMG
+                stage[s]["kernels"].append(k)
+    open(os.path.join(OUT, "%s_kernel_counters.txt" % TAG), "w").write("\n".join(lines) + "\n")
+    stage["_source"] = "%s_kernel_counters.txt (rocprofv3 --pmc passes of tools/prof_run.py, per image)" % TAG
+    json.dump(stage, open(os.path.join(OUT, "%s_kernel_counters.json" % TAG), "w"), indent=1)
+    print(json.dumps(stage)[:1500])

@@ -232,6 +232,11 @@ typedef struct popsift_hip_match {
  * descriptor of `l` among the descriptors of `r`; out has l's descriptor count entries (host memory).
  * Sets on different GPUs are allowed (the right set is copied to the left set's GPU). */
 int popsift_hip_match_sets(const popsift_hip_devfeatures* l, const popsift_hip_devfeatures* r, popsift_hip_match* out);
+/* Which kernels popsift_hip_match_sets uses, process-wide (tests compare the paths; results are identical):
+ * AUTO (default): matrix-core screening + exact re-rank from 4e6 pairs on, the exact brute-force kernel below;
+ * EXACT: the exact kernel only; SCREEN: screening for every size. */
+enum { POPSIFT_HIP_MATCH_AUTO = 0, POPSIFT_HIP_MATCH_EXACT = 1, POPSIFT_HIP_MATCH_SCREEN = 2 };
+int popsift_hip_match_set_path(int path);
 
 int popsift_hip_get_report(const popsift_hip_ctx* ctx, popsift_hip_report* rep);
 /* profile != 0: bracket every blur-level launch with HIP events (serialises the

@@ -105,6 +105,7 @@ SYMBOLS = [
     ("popsift_hip_devfeatures_from_host", C.c_int, [C.c_int, _vp, C.c_int, C.POINTER(_vp)]),
     ("popsift_hip_devfeatures_download", C.c_int, [_vp, _vp, _vp]),
     ("popsift_hip_match_sets", C.c_int, [_vp, _vp, _vp]),
+    ("popsift_hip_match_set_path", C.c_int, [C.c_int]),
     ("popsift_hip_get_report", C.c_int, [_vp, C.POINTER(Report)]),
     ("popsift_hip_set_profile", C.c_int, [_vp, C.c_int]),
     ("popsift_hip_octave_dims", C.c_int, [_vp, C.c_int, _ip, _ip]),
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("popsift_hip_rerun_keypoint_stages", C.c_int, [_vp]),
     ("popsift_hip_debug_set", C.c_int, [_vp, C.c_int, C.c_int]),
 ]
+MATCH_AUTO, MATCH_EXACT, MATCH_SCREEN = 0, 1, 2
 STAGES = ("pyramid", "detect", "refine", "orientation", "scan", "descriptor")
 DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC = 1, 2, 3, 4
 

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -1086,6 +1087,15 @@ int popsift_hip_devfeatures_download(const popsift_hip_devfeatures* f, float* de
     return POPSIFT_HIP_OK;
 }
 
+static std::atomic<int> g_match_path{POPSIFT_HIP_MATCH_AUTO};
+
+int popsift_hip_match_set_path(int path)
+{
+    if (path < POPSIFT_HIP_MATCH_AUTO || path > POPSIFT_HIP_MATCH_SCREEN) return POPSIFT_HIP_ERR_INVALID;
+    g_match_path.store(path);
+    return POPSIFT_HIP_OK;
+}
+
 int popsift_hip_match_sets(const popsift_hip_devfeatures* lc, const popsift_hip_devfeatures* r, popsift_hip_match* out)
 {
     if (!lc || !r || (lc->n_desc > 0 && !out)) return POPSIFT_HIP_ERR_INVALID;
@@ -1109,10 +1119,9 @@ int popsift_hip_match_sets(const popsift_hip_devfeatures* lc, const popsift_hip_
     if (rc == POPSIFT_HIP_OK && !l->m_host) ok(hipHostMalloc(&l->m_host, out_bytes, hipHostMallocDefault));
     /* large problems: matrix-core screening + exact re-rank (match_mfma.hip); small ones and
      * POPSIFT_HIP_MATCH_EXACT=1: the exact brute-force kernel alone (match.hip) */
-    const char*  e_exact = getenv("POPSIFT_HIP_MATCH_EXACT");      /* read per call: tests switch paths */
-    const char*  e_min = getenv("POPSIFT_HIP_MATCH_SCREEN_MIN");  /* pairs from which screening pays */
-    const double min_pairs = e_min ? atof(e_min) : 4.0e6;
-    const bool   screen = !(e_exact && atoi(e_exact) != 0) && (double)l->n_desc * (double)r->n_desc >= min_pairs;
+    const int    path = g_match_path.load();
+    const bool   screen = path == POPSIFT_HIP_MATCH_SCREEN ||
+                        (path == POPSIFT_HIP_MATCH_AUTO && (double)l->n_desc * (double)r->n_desc >= 4.0e6);
     const int         n_split = match_splits(l->n_desc, r->n_desc);
     const int         s_split = screen ? screen_splits(l->n_desc, r->n_desc) : 1;
     /* rows the screening pass cannot decide are few: the first REDO_CAP of them are matched with the right set split
@@ -1164,11 +1173,6 @@ int popsift_hip_match_sets(const popsift_hip_devfeatures* lc, const popsift_hip_
     if (rc == POPSIFT_HIP_OK && ok(hipMemcpyAsync(l->m_host, l->m_out, out_bytes, hipMemcpyDeviceToHost, s)) &&
         ok(hipStreamSynchronize(s)))
         memcpy(out, l->m_host, out_bytes);
-    if (rc == POPSIFT_HIP_OK && screen && getenv("POPSIFT_HIP_MATCH_DEBUG")) {
-        int redo = 0;
-        (void)hipMemcpy(&redo, l->m_redo, sizeof(int), hipMemcpyDeviceToHost);
-        fprintf(stderr, "popsift_hip_match_sets: %d x %d, %d rows left to the exact kernel\n", l->n_desc, r->n_desc, redo);
-    }
     if (r_copy) (void)hipFree(r_copy);
     return rc;
 }

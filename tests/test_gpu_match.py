@@ -82,10 +82,19 @@ def test_full_size_sets(oracle_mod, gpu_hip):
     assert np.all(m["dist_best"] <= m["dist_second"])
 
 
+@pytest.fixture
+def match_path(gpu_hip):
+    """popsift_hip_match_set_path for the duration of a test"""
+    def set_path(p):
+        assert gpu_hip.lib().popsift_hip_match_set_path(p) == 0
+    yield set_path
+    gpu_hip.lib().popsift_hip_match_set_path(gpu_hip.MATCH_AUTO)
+
+
 @pytest.mark.parametrize("nl,nr", [(1, 1), (2, 3), (5, 4), (33, 5), (130, 129), (257, 1000), (1500, 2100)])
-def test_screened_path_matches_the_oracle(oracle_mod, gpu_hip, monkeypatch, nl, nr):
+def test_screened_path_matches_the_oracle(oracle_mod, gpu_hip, match_path, nl, nr):
     """Matrix-core screening + exact re-rank (match_mfma.hip) forced for every size, against the oracle."""
-    monkeypatch.setenv("POPSIFT_HIP_MATCH_SCREEN_MIN", "0")
+    match_path(gpu_hip.MATCH_SCREEN)
     rng = np.random.default_rng(nl * 31 + nr)
     l = rng.random((nl, 128), np.float32)
     l /= np.linalg.norm(l, axis=1, keepdims=True)
@@ -97,10 +106,10 @@ def test_screened_path_matches_the_oracle(oracle_mod, gpu_hip, monkeypatch, nl, 
     assert_same(oracle_mod.match(l, r), L.match(R))
 
 
-def test_screening_margin_cases(oracle_mod, gpu_hip, monkeypatch):
+def test_screening_margin_cases(oracle_mod, gpu_hip, match_path):
     """Rows the screening pass cannot decide -- exact duplicates and near-ties in the right set, more of them than
     it tracks -- go to the exact kernel; large norms (norm_multi) scale the margin."""
-    monkeypatch.setenv("POPSIFT_HIP_MATCH_SCREEN_MIN", "0")
+    match_path(gpu_hip.MATCH_SCREEN)
     rng = np.random.default_rng(7)
     l = rng.random((300, 128), np.float32)
     r = rng.random((900, 128), np.float32)
@@ -120,6 +129,6 @@ def test_screening_margin_cases(oracle_mod, gpu_hip, monkeypatch):
     r = rng.random((5000, 128), np.float32)
     L, R = gpu_hip.DevFeatures.from_host(l), gpu_hip.DevFeatures.from_host(r)
     a = L.match(R)
-    monkeypatch.setenv("POPSIFT_HIP_MATCH_EXACT", "1")
+    match_path(gpu_hip.MATCH_EXACT)
     b = L.match(R)
     assert_same(a, b)

@@ -370,7 +370,9 @@ def main():
                         f.write(im.tobytes())
                 r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(16 * world), "--pgm", ",".join(pgms)],
                                    capture_output=True, text=True, timeout=180,
-                                   env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE="4", POPSIFT_DEVICES=devs))
+                                   env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE="4", POPSIFT_DEVICES=devs,
+                                            # every job in flight holds ~82 MB of pinned result blocks: let the pool keep them
+                                            POPSIFT_PINNED_CACHE_MB=str(16 * world * 100)))
                 extra["host_to_host_cpp_api"] = json.loads(r.stdout.strip().splitlines()[-1])
                 extra["host_to_host_cpp_api"]["devices"] = devs
             except Exception as e:  # a reported extra: never fail the bench line over it

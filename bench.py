@@ -368,13 +368,18 @@ def main():
                     with open(pgms[-1], "wb") as f:
                         f.write(b"P5\n%d %d\n255\n" % (W, H))
                         f.write(im.tobytes())
-                r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(16 * world), "--pgm", ",".join(pgms)],
-                                   capture_output=True, text=True, timeout=180,
-                                   env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE="4", POPSIFT_DEVICES=devs,
-                                            # every job in flight holds ~82 MB of pinned result blocks: let the pool keep them
-                                            POPSIFT_PINNED_CACHE_MB=str(16 * world * 100)))
-                extra["host_to_host_cpp_api"] = json.loads(r.stdout.strip().splitlines()[-1])
-                extra["host_to_host_cpp_api"]["devices"] = devs
+                def cpp_leg(per_dev):
+                    r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(4 * per_dev * world),
+                                        "--pgm", ",".join(pgms)], capture_output=True, text=True, timeout=180,
+                                       env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE=str(per_dev), POPSIFT_DEVICES=devs,
+                                                # every job in flight holds ~82 MB of pinned result blocks: let the pool keep them
+                                                POPSIFT_PINNED_CACHE_MB=str(4 * per_dev * world * 100)))
+                    out = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["devices"] = devs
+                    return out
+                extra["host_to_host_cpp_api"] = cpp_leg(4)
+                # one context per GPU: its download of image i runs under the kernels of image i+1 (fetch_begin / fetch_end)
+                extra["host_to_host_cpp_api_one_context"] = cpp_leg(1)
             except Exception as e:  # a reported extra: never fail the bench line over it
                 extra["host_to_host_cpp_api"] = {"error": str(e)[:200]}
         leg("cpp_api")

@@ -191,6 +191,20 @@ int popsift_hip_wait(popsift_hip_ctx* ctx, int* n_features, int* n_descriptors);
  * feats: n_features entries; desc: n_descriptors * 128 floats. */
 int popsift_hip_fetch(popsift_hip_ctx* ctx, popsift_hip_feature* feats, size_t feats_cap,
                       float* desc, size_t desc_cap);
+/* The same download split in two, so that one context overlaps it with the kernels of its next image
+ * (the reference serialises them: Pyramid::get_descriptors blocks on its two copies, sift_pyramid.cu:296-321,
+ * before PopSift::extractDownloadLoop takes the next job, popsift.cpp:187-213).
+ * fetch_begin: requires a finished image (it waits like popsift_hip_wait), starts the two copies on the context's
+ * copy stream and returns at once; the context switches to its second result slab, so the next submit / wait may
+ * follow immediately.  feats / desc should be pinned (popsift_hip_host_alloc) -- a pageable target makes the copy
+ * synchronous -- and must stay untouched until fetch_end returns.
+ * fetch_end: blocks until that download has landed.  ERR_STATE without a pending download.
+ * After fetch_begin the image's results are no longer in the context: fetch, fetch_begin, results_dev and
+ * clone_results return ERR_STATE until another image has been submitted.  A second fetch_begin (for the next image)
+ * first waits for the pending download; so does ctx_destroy. */
+int popsift_hip_fetch_begin(popsift_hip_ctx* ctx, popsift_hip_feature* feats, size_t feats_cap,
+                            float* desc, size_t desc_cap);
+int popsift_hip_fetch_end(popsift_hip_ctx* ctx);
 /* Device-resident results (FeaturesDev analogue, features.h:98-118): pointers
  * stay valid until the next submit on this context. */
 int popsift_hip_results_dev(popsift_hip_ctx* ctx, const void** d_feats, const void** d_desc);

@@ -94,6 +94,8 @@ SYMBOLS = [
     ("popsift_hip_submit_dev_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("popsift_hip_wait", C.c_int, [_vp, _ip, _ip]),
     ("popsift_hip_fetch", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    ("popsift_hip_fetch_begin", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    ("popsift_hip_fetch_end", C.c_int, [_vp]),
     ("popsift_hip_results_dev", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     ("popsift_hip_host_alloc", _vp, [C.c_size_t]),
     ("popsift_hip_host_free", None, [_vp]),
@@ -221,6 +223,62 @@ class DevFeatures:
             pass
 
 
+class PendingFetch:
+    """A download started by Context.fetch_begin; result() waits for it (popsift_hip_fetch_end)."""
+
+    def __init__(self, ctx, nf, nd, pinned):
+        self._ctx, self._done = ctx, False
+        self._fbytes, self._dbytes = max(nf, 1) * FEATURE_DTYPE.itemsize, max(nd, 1) * 512
+        self._pin = []
+        if pinned:
+            for n in (self._fbytes, self._dbytes):
+                p = lib().popsift_hip_host_alloc(n)
+                if not p:
+                    self._release()
+                    raise MemoryError("popsift_hip_host_alloc(%d)" % n)
+                self._pin.append(p)
+            fb = (C.c_char * self._fbytes).from_address(self._pin[0])
+            db = (C.c_char * self._dbytes).from_address(self._pin[1])
+            self._feats = np.frombuffer(fb, FEATURE_DTYPE, nf)
+            self._desc = np.frombuffer(db, np.float32, nd * 128).reshape(nd, 128)
+        else:
+            self._feats = np.zeros(nf, FEATURE_DTYPE)
+            self._desc = np.zeros((nd, 128), np.float32)
+        try:
+            ctx._chk(lib().popsift_hip_fetch_begin(ctx._h, self._feats.ctypes.data, nf, self._desc.ctypes.data, nd * 128),
+                     "popsift_hip_fetch_begin")
+        except Exception:
+            self._release()
+            raise
+
+    def _release(self):
+        for p in self._pin:
+            lib().popsift_hip_host_free(p)
+        self._pin = []
+
+    def _landed(self):
+        """the download is complete (fetch_end, or a later fetch_begin on the same context, has waited for it)"""
+        self._done = True
+        if self._pin:
+            self._feats, self._desc = self._feats.copy(), self._desc.copy()
+            self._release()
+
+    def result(self):
+        """(feats, desc) as ordinary numpy arrays (copied out of the pinned blocks, which are released)."""
+        if not self._done:
+            self._ctx._chk(lib().popsift_hip_fetch_end(self._ctx._h), "popsift_hip_fetch_end")
+            self._landed()
+        return self._feats, self._desc
+
+    def __del__(self):
+        try:
+            if not self._done and self._ctx._h:
+                lib().popsift_hip_fetch_end(self._ctx._h)
+            self._release()
+        except Exception:
+            pass
+
+
 class Context:
     """One extraction context (popsift_hip_ctx) on one GPU."""
 
@@ -290,6 +348,16 @@ class Context:
         self._chk(lib().popsift_hip_fetch(self._h, feats.ctypes.data, nf, desc.ctypes.data, nd * 128),
                   "popsift_hip_fetch")
         return feats, desc
+
+    def fetch_begin(self, pinned=True):
+        """Start the download of the finished image and return a handle; the context is free for the next submit.
+        handle.result() (popsift_hip_fetch_end) -> (feats, desc).  pinned: page-locked targets (asynchronous copy)."""
+        nf, nd = self.wait()
+        prev = getattr(self, "_pending", None)
+        self._pending = PendingFetch(self, nf, nd, pinned)   # the C call waits for an earlier pending download first
+        if prev is not None and not prev._done:
+            prev._landed()
+        return self._pending
 
     def report(self):
         r = Report()

@@ -92,6 +92,15 @@ struct popsift_hip_ctx {
     float2*  d_rot = nullptr; /* (cos, sin) of every descriptor's orientation, correctly rounded (k_scan_apply) */
     float*   d_desc = nullptr;
     int      desc_cap = 0;
+    /* second result slab (popsift_hip_fetch_begin): the download of image i reads one slab on copy_stream while the
+     * kernels of image i+1 write the other.  Invariant: alt caps <= the current slab's; fetch_begin equalises and swaps */
+    popsift_hip_feature* alt_feats = nullptr;
+    size_t   alt_feats_cap = 0;
+    float*   alt_desc = nullptr;
+    int      alt_desc_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    bool     copy_pending = false;  /* a fetch_begin download has not been waited for */
+    bool     results_moved = false; /* the finished image's results went to fetch_begin: the current slab is stale */
     Counters* d_ct = nullptr;
     Counters* h_ct = nullptr; /* pinned */
     PyrDesc*  d_pd = nullptr; /* device copy of pd (kernels index octaves dynamically) */
@@ -586,6 +595,7 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->have_image = true;
     c->finished = false;
+    c->results_moved = false;
     return 0;
 }
 
@@ -663,6 +673,24 @@ int finish(popsift_hip_ctx* c)
         }
     }
     c->finished = true;
+    return 0;
+}
+
+/* waits for the download popsift_hip_fetch_begin started, if one is pending */
+int drain_copy(popsift_hip_ctx* c)
+{
+    if (!c->copy_pending) return 0;
+    c->copy_pending = false;
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    return 0;
+}
+
+/* results of the finished image are readable from the current slab (not yet handed to fetch_begin) */
+int results_here(popsift_hip_ctx* c)
+{
+    if (int rc = finish(c)) return rc;
+    if (c->results_moved)
+        return fail(c, POPSIFT_HIP_ERR_STATE, "the results of this image were handed to popsift_hip_fetch_begin");
     return 0;
 }
 
@@ -819,12 +847,10 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
         {
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-#ifndef KP_GRID_MULT
-#define KP_GRID_MULT 1
-#endif
-            c->kp_waves = std::max(cus, 8) * 32 * 8 * KP_GRID_MULT; /* a multiple of 32 */
+            c->kp_waves = std::max(cus, 8) * 32 * 8; /* a multiple of 32 */
         }
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
         HIP_TRY(c, hipEventCreate(&c->ev_end));
         for (int k = 0; k <= POPSIFT_HIP_STAGE_COUNT; k++) HIP_TRY(c, hipEventCreate(&c->ev_stage[k]));
@@ -852,6 +878,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (!c) return POPSIFT_HIP_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& ep : c->blur_events) {
         (void)hipEventDestroy(ep.a);
         (void)hipEventDestroy(ep.b);
@@ -873,6 +900,8 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_rot) (void)hipFree(c->d_rot);
     if (c->d_desc) (void)hipFree(c->d_desc);
+    if (c->alt_feats) (void)hipFree(c->alt_feats);
+    if (c->alt_desc) (void)hipFree(c->alt_desc);
     if (c->d_ct) (void)hipFree(c->d_ct);
     if (c->d_pd) (void)hipFree(c->d_pd);
     if (c->h_pd) (void)hipHostFree(c->h_pd);
@@ -881,6 +910,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->h_ct) (void)hipHostFree(c->h_ct);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
     return POPSIFT_HIP_OK;
 }
@@ -924,7 +954,7 @@ int popsift_hip_wait(popsift_hip_ctx* c, int* n_features, int* n_descriptors)
 int popsift_hip_fetch(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t feats_cap, float* desc, size_t desc_cap)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
-    if (int rc = finish(c)) return rc;
+    if (int rc = results_here(c)) return rc;
     POPSIFT_RANGE("popsift_hip: fetch");
     const size_t nf = (size_t)c->rep.ext_total, nd = (size_t)c->rep.ori_total;
     if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
@@ -936,10 +966,50 @@ int popsift_hip_fetch(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t fea
     return POPSIFT_HIP_OK;
 }
 
+int popsift_hip_fetch_begin(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t feats_cap, float* desc, size_t desc_cap)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = results_here(c)) return rc;
+    POPSIFT_RANGE("popsift_hip: fetch_begin");
+    const size_t nf = (size_t)c->rep.ext_total, nd = (size_t)c->rep.ori_total;
+    if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
+    if (feats_cap < nf || desc_cap < nd * 128) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    /* the other slab may still be the source of the previous download */
+    if (int rc = drain_copy(c)) return rc;
+    /* nothing has been issued or swapped yet: a failed allocation leaves the results where they are (plain fetch works) */
+    if (int rc = grow(c, &c->alt_feats, &c->alt_feats_cap, c->feats_cap)) return rc;
+    if (c->alt_desc_cap < c->desc_cap) {
+        if (c->alt_desc) HIP_TRY(c, hipFree(c->alt_desc));
+        c->alt_desc = nullptr;
+        c->alt_desc_cap = 0;
+        HIP_TRY(c, ctx_malloc(c, (void**)&c->alt_desc, (size_t)c->desc_cap * 128 * sizeof(float)));
+        c->alt_desc_cap = c->desc_cap;
+    }
+    /* finish() has synchronised the compute stream: the slab is complete, and copy_stream needs no event to wait on */
+    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, c->d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->copy_stream));
+    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+    std::swap(c->d_feats, c->alt_feats);
+    std::swap(c->feats_cap, c->alt_feats_cap);
+    std::swap(c->d_desc, c->alt_desc); /* both hold desc_cap descriptors now; d_map / d_rot stay with the context */
+    c->copy_pending = true;
+    c->results_moved = true;
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_fetch_end(popsift_hip_ctx* c)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    POPSIFT_RANGE("popsift_hip: fetch_end");
+    if (!c->copy_pending) return fail(c, POPSIFT_HIP_ERR_STATE, "no download was started with popsift_hip_fetch_begin");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return drain_copy(c);
+}
+
 int popsift_hip_results_dev(popsift_hip_ctx* c, const void** d_feats, const void** d_desc)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
-    if (int rc = finish(c)) return rc;
+    if (int rc = results_here(c)) return rc;
     if (d_feats) *d_feats = c->d_feats;
     if (d_desc) *d_desc = c->d_desc;
     return POPSIFT_HIP_OK;
@@ -951,7 +1021,7 @@ int popsift_hip_clone_results(popsift_hip_ctx* c, popsift_hip_devfeatures** out)
 {
     if (!c || !out) return POPSIFT_HIP_ERR_INVALID;
     *out = nullptr;
-    if (int rc = finish(c)) return rc;
+    if (int rc = results_here(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     popsift_hip_devfeatures* f = new (std::nothrow) popsift_hip_devfeatures();
     if (!f) return fail(c, POPSIFT_HIP_ERR_OOM, "out of host memory");
@@ -1302,6 +1372,7 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* c)
     if (int rc = enqueue_keypoint_stages(c)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->finished = false;
+    c->results_moved = false;
     return POPSIFT_HIP_OK;
 }
 

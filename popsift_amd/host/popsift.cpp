@@ -258,6 +258,30 @@ void PopSift::start_workers(int w, int h)
     g_live_pipelines++;
 }
 
+/* POD features -> popsift::Feature with descriptor pointers into the job's own block (prep_features, sift_pyramid.cu:249-279) */
+static void convert_features(const popsift_hip_feature* pod, int nf, popsift::FeaturesHost* features)
+{
+    popsift::Feature*    out = features->getFeatures();
+    popsift::Descriptor* base = features->getDescriptors();
+    for (int i = 0; i < nf; i++) {
+        const popsift_hip_feature& s = pod[i];
+        popsift::Feature&          f = out[i];
+        f.debug_octave = s.debug_octave;
+        f.xpos = s.xpos;
+        f.ypos = s.ypos;
+        f.sigma = s.sigma;
+        f.num_ori = s.num_ori;
+        for (int k = 0; k < ORIENTATION_MAX_COUNT; k++) {
+            f.orientation[k] = s.orientation[k];
+            f.desc[k] = s.desc_idx[k] >= 0 ? base + s.desc_idx[k] : 0;
+        }
+    }
+}
+
+/* One worker = one context.  Where the reference's extractDownloadLoop (popsift.cpp:187-213) downloads image i before
+ * it looks at image i+1, this loop starts the download (popsift_hip_fetch_begin: copy stream, second result slab) and
+ * submits image i+1 first -- its kernels run under the PCIe transfer and under the host-side conversion of image i.
+ * With nothing queued the pending download is completed at once, so a lone job sees no added latency. */
 void PopSift::worker_loop(Worker* me)
 {
     {
@@ -265,14 +289,38 @@ void PopSift::worker_loop(Worker* me)
         if (popsift_hip_device_numa_node(me->device, &node) == POPSIFT_HIP_OK) bind_to_numa_node(node);
         popsift::setPinnedPoolNode(node); /* result blocks this thread takes come from / go to its node's free list */
     }
+    /* --log dumps read the context's planes after the image: keep those runs strictly serial */
+    const bool overlap = _config.getLogMode() != popsift::Config::All;
+    struct {
+        SiftJob*               job = 0;
+        popsift::FeaturesHost* features = 0;
+        int                    nf = 0;
+    } pending;
+    auto complete_pending = [&]() {
+        if (!pending.job) return;
+        if (popsift_hip_fetch_end(me->ctx) != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
+        convert_features((const popsift_hip_feature*)me->pod, pending.nf, pending.features);
+        pending.job->setFeatures(pending.features);
+        pending.job = 0;
+    };
     for (;;) {
-        SiftJob* job;
+        SiftJob* job = 0;
+        bool     quit = false;
         {
             std::unique_lock<std::mutex> lk(_mtx);
-            _cv.wait(lk, [&] { return !_queue.empty(); });
-            job = _queue.front();
-            if (job == 0) return; /* shutdown marker stays for the other workers */
-            _queue.pop();
+            if (!pending.job) _cv.wait(lk, [&] { return !_queue.empty(); });
+            if (!_queue.empty()) {
+                job = _queue.front();
+                if (job == 0)
+                    quit = true; /* shutdown marker stays for the other workers */
+                else
+                    _queue.pop();
+            }
+        }
+        if (quit || !job) {
+            complete_pending();
+            if (quit) return;
+            continue;
         }
         POPSIFT_RANGE("PopSift job (submit, wait, fetch)");
         int rc;
@@ -281,8 +329,10 @@ void PopSift::worker_loop(Worker* me)
                                         job->getWidth());
         else
             rc = popsift_hip_submit_u8(me->ctx, job->getImageData(), job->getWidth(), job->getHeight(), job->getWidth());
+        if (rc != POPSIFT_HIP_OK) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
+        complete_pending(); /* the previous image's download and conversion, under this image's kernels */
         int nf = 0, nd = 0;
-        if (rc == POPSIFT_HIP_OK) rc = popsift_hip_wait(me->ctx, &nf, &nd);
+        rc = popsift_hip_wait(me->ctx, &nf, &nd);
         if (rc != POPSIFT_HIP_OK) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
 
         if (_proc_mode == popsift::Config::MatchingMode) {
@@ -306,23 +356,17 @@ void PopSift::worker_loop(Worker* me)
                 if (!me->pod) DIE("Memory limitation: failed to allocate the feature staging buffer");
             }
             popsift_hip_feature* pod = (popsift_hip_feature*)me->pod;
+            if (overlap) {
+                rc = popsift_hip_fetch_begin(me->ctx, pod, me->pod_cap, (float*)features->getDescriptors(), (size_t)nd * 128);
+                if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
+                pending.job = job;
+                pending.features = features;
+                pending.nf = nf;
+                continue;
+            }
             rc = popsift_hip_fetch(me->ctx, pod, me->pod_cap, (float*)features->getDescriptors(), (size_t)nd * 128);
             if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
-            popsift::Feature*    out = features->getFeatures();
-            popsift::Descriptor* base = features->getDescriptors();
-            for (int i = 0; i < nf; i++) {
-                const popsift_hip_feature& s = pod[i];
-                popsift::Feature&          f = out[i];
-                f.debug_octave = s.debug_octave;
-                f.xpos = s.xpos;
-                f.ypos = s.ypos;
-                f.sigma = s.sigma;
-                f.num_ori = s.num_ori;
-                for (int k = 0; k < ORIENTATION_MAX_COUNT; k++) {
-                    f.orientation[k] = s.orientation[k];
-                    f.desc[k] = s.desc_idx[k] >= 0 ? base + s.desc_idx[k] : 0;
-                }
-            }
+            convert_features(pod, nf, features);
         }
         if (_config.getLogMode() == popsift::Config::All) {
             /* popsift.cpp:201-209; with several workers the dumps of concurrent images overwrite

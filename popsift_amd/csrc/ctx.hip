@@ -370,7 +370,7 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h)
             if (int rc = grow(c, &c->d_iext2, &c->iext2_cap, need_ext)) return rc;
         c->ext_cap = need_ext;
     }
-    if (int rc = grow(c, &c->d_partial, &c->partial_cap, need_ext / scan_chunk() + 2)) return rc;
+    if (int rc = grow(c, &c->d_partial, &c->partial_cap, (need_ext / scan_chunk() + 2) * scan_partials_per_chunk())) return rc;
     /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
     if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
         return rc;
@@ -485,6 +485,8 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
         a.shift = shift;
         /* weights of the linear upscale are exactly {0, 1/2}: k_blur_tile's copy / average path */
         a.fast2x = (c->p.upscale_factor == 1.0f && shift == 1.0f && od.w == 2 * c->in_w && od.h == 2 * c->in_h) ? 1 : 0;
+        a.zero = (int*)c->d_ct; /* this launch clears the image's counters (enqueue_keypoint_stages(c, true)) */
+        a.zero_words = (int)(sizeof(Counters) / sizeof(int));
         const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * (double)od.w * od.h;
         if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
     }
@@ -516,12 +518,13 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 /* Pyramid::step2 + prep_features: extrema -> orientation -> scan -> descriptors -> features */
 InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iext2 : c->d_iext; }
 
-int enqueue_keypoint_stages(popsift_hip_ctx* c)
+/* counters_cleared: the level-0 launch of this image has zeroed d_ct (submit); re-runs clear it here */
+int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
 {
     POPSIFT_RANGE("popsift_hip: keypoint stages");
     const bool stages = (c->profile == 2);
     auto       mark = [&](int k) -> hipError_t { return stages ? hipEventRecord(c->ev_stage[k], c->stream) : hipSuccess; };
-    HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
+    if (!counters_cleared) HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DETECT)); /* = end of the pyramid stage */
     HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_ovf, c->d_iext,
                               c->stream, stages ? c->ev_stage[POPSIFT_HIP_STAGE_REFINE] : nullptr));
@@ -591,7 +594,7 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
     HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
     if (c->profile == 2) HIP_TRY(c, hipEventRecord(c->ev_stage[POPSIFT_HIP_STAGE_PYRAMID], c->stream));
     if (int rc = enqueue_pyramid(c, d_img, is_f32, dpitch)) return rc;
-    if (int rc = enqueue_keypoint_stages(c)) return rc;
+    if (int rc = enqueue_keypoint_stages(c, true)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->have_image = true;
     c->finished = false;

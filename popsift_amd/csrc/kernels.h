@@ -27,6 +27,10 @@ struct BlurArgs {
      * s_pyramid_build.cu:50-71), written by the same launch; null otherwise */
     float*       next0;
     int          next_pitch;
+    /* level 0 only (the first launch of an image): per-image counters this launch clears, so that the image needs no
+     * separate fill launch before detection; null otherwise */
+    int*         zero;
+    int          zero_words;
 };
 
 int        blur_tile_w();
@@ -46,7 +50,8 @@ hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
 /* ohist: 36 floats per extremum (the raw orientation histogram), hist_cap extrema */
 hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, const InitExt* iext,
                               float* ohist, int hist_cap, int blocks, hipStream_t s);
-int        scan_chunk(); /* extrema per scan workgroup */
+int        scan_chunk(); /* extrema per k_scan_apply workgroup */
+int        scan_partials_per_chunk(); /* partial sums k_scan_local leaves per scan_chunk() extrema */
 hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
                        int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot,
                        popsift_hip_feature* feats, int desc_cap, hipStream_t s);

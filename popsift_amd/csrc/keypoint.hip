@@ -461,15 +461,21 @@ __device__ __forceinline__ int ori_peaks_quad(const float* __restrict__ hsrc, in
  * Exclusive prefix sum of num_ori over all extrema -> idx_ori, the reverse map
  * descriptor -> extremum, and the totals (replaces ori_prefix_sum's single
  * 32x32 block looping over everything, s_orientation.cu:303-345).  Two launches:
- * k_scan_local scans 2048-extrema chunks and leaves one partial per chunk;
- * k_scan_apply adds the sum of the preceding partials (<= 440 values for the
- * default 9 x 100000 capacity, summed redundantly per workgroup) and writes the
- * map and the counters.
+ * k_scan_local scans 64-extrema chunks and leaves one partial per chunk;
+ * k_scan_apply (256 extrema per workgroup) adds the sum of the preceding partials
+ * (<= 14 100 values for the default 9 x 100000 capacity, ~1 200 for a 1080p image,
+ * summed redundantly per workgroup) and writes the map and the counters.
  */
 /* extrema per lane: 1 -- the per-extremum work of k_scan_apply (feature record, double-precision cos / sin)
  * is serial per lane, so wide beats deep (8 per lane: 22.8 us, 2: 10.2 us, 1: 7.5 us) */
 constexpr int SCAN_ITEMS = 1;
 constexpr int SCAN_CHUNK = 256 * SCAN_ITEMS;
+/* k_scan_local: lanes per workgroup (four per extremum) and the extrema it scans; SCAN_SUB local chunks per apply chunk.
+ * The kernel is a latency chain per workgroup (record, histogram, peaks, scan, store), so many small workgroups beat
+ * few large ones: 128 / 256 / 512 / 1024 lanes -> 14.0 / 13.2 / 14.3 / 19.9 us for the 77 000 extrema of a 1080p image */
+constexpr int SCAN_LT = 256;
+constexpr int SCAN_LCHUNK = SCAN_LT / 4;
+constexpr int SCAN_SUB = SCAN_CHUNK / SCAN_LCHUNK;
 
 __device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConsts& sc, int n_oct)
 {
@@ -478,13 +484,13 @@ __device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConst
     return acc;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
+__global__ __launch_bounds__(SCAN_LT) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
                                                      const Counters* __restrict__ ct, const InitExt* __restrict__ iext,
                                                      const float* __restrict__ ohist, int hist_cap,
                                                      Ext* __restrict__ ext, int* __restrict__ partial)
 {
-    static_assert(SCAN_CHUNK == 256, "four lanes per extremum, 1024 lanes per workgroup");
-    __shared__ int s_wsum[16];
+    static_assert(SCAN_CHUNK % SCAN_LCHUNK == 0 && SCAN_LT % 64 == 0, "four lanes per extremum, whole waves");
+    __shared__ int s_wsum[SCAN_LT / 64];
     __shared__ int s_ps[PS_MAX_OCT + 1];
     const int      n_oct = pdp->n_oct;
     if (threadIdx.x == 0) ext_prefix(ct, sc, n_oct, s_ps);
@@ -493,8 +499,8 @@ __global__ __launch_bounds__(1024) void k_scan_local(const PyrDesc* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = tid & 3;
     /* the launch is sized for the device, not for the capacity of the lists: workgroups stride over the chunks */
-    for (int chunk = blockIdx.x; chunk * SCAN_CHUNK < total; chunk += gridDim.x) {
-    const int  base = chunk * SCAN_CHUNK;
+    for (int chunk = blockIdx.x; chunk * SCAN_LCHUNK < total; chunk += gridDim.x) {
+    const int  base = chunk * SCAN_LCHUNK;
     const int  g = base + (tid >> 2);
     const bool valid = g < total;
     const int  gc = min(g, total - 1); /* lanes beyond the list compute along (the quad exchanges need them) */
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(1024) void k_scan_local(const PyrDesc* __restrict__
         e.idx_ori = woff + incl - self; /* chunk-local for now */
         ext[g] = e;
     }
-    if (tid == 1023) partial[chunk] = woff + incl;
+    if (tid == SCAN_LT - 1) partial[chunk] = woff + incl;
     __syncthreads(); /* s_wsum is reused by the next chunk */
     }
 }
@@ -569,14 +575,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
     for (int chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
     const int base = chunk * SCAN_CHUNK;
 
-    /* offset of this chunk = sum of the partials of all preceding chunks */
+    /* offset of this chunk = sum of the partials of all preceding chunks (SCAN_SUB local chunks per chunk here) */
     int acc = 0;
-    for (int b = tid; b < chunk; b += 256) acc += partial[b];
+    for (int b = tid; b < chunk * SCAN_SUB; b += 256) acc += partial[b];
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
     if (lane == 0) s_red[wave] = acc;
     __syncthreads();
-    const int offset = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const int chunk_offset = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    /* ... plus the local chunks of this chunk that precede the lane's own */
+    int offset = chunk_offset;
+    for (int k = 0; k < (tid * SCAN_ITEMS) / SCAN_LCHUNK; k++) offset += partial[chunk * SCAN_SUB + k];
 
     const int g0 = base + tid * SCAN_ITEMS;
 #pragma unroll
@@ -616,7 +625,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
         }
     }
     if (tid == 0 && chunk == nb - 1) {
-        ct->ori_total = offset + partial[chunk];
+        int last = chunk_offset;
+        for (int k = 0; k < SCAN_SUB && (chunk * SCAN_SUB + k) * SCAN_LCHUNK < total; k++) last += partial[chunk * SCAN_SUB + k];
+        ct->ori_total = last;
         ct->ext_total = total;
         for (int o = 0; o < PS_MAX_OCT; o++) {
             /* the reference clamps with atomicMin in the extrema kernel, s_extrema.cu:558 */
@@ -1298,12 +1309,13 @@ hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, co
                        popsift_hip_feature* feats, int desc_cap, hipStream_t s)
 {
     /* n_chunks is the capacity of the lists; a 1080p image fills ~300 chunks */
-    hipLaunchKernelGGL(k_scan_local, dim3(std::min(n_chunks, 512)), dim3(1024), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
+    hipLaunchKernelGGL(k_scan_local, dim3(std::min(n_chunks * SCAN_SUB, 512 * SCAN_SUB)), dim3(SCAN_LT), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
     hipLaunchKernelGGL(k_scan_apply, dim3(std::min(n_chunks, 1024)), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, feats, desc_cap);
     return hipGetLastError();
 }
 
 int scan_chunk() { return SCAN_CHUNK; }
+int scan_partials_per_chunk() { return SCAN_SUB; }
 
 hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, Counters* ct,
                               const Ext* ext, const int* map, const float2* rot, float* desc, int desc_cap, int blocks,

@@ -430,6 +430,8 @@ template <int HALO, int MODE, int TH, int NT>
 __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
 {
     __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, TH>()];
+    if (MODE != 0 && a.zero != nullptr && blockIdx.x == gridDim.x - 1)
+        for (int i = threadIdx.x; i < a.zero_words; i += NT) a.zero[i] = 0;
     blur_tile_body<HALO, MODE, TH, NT>(a, blockIdx.x, s_t);
 }
 

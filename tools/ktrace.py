@@ -13,5 +13,5 @@ for r in last:
     name = name.split('(')[0][:26]
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     tot += e - s
-    print("%-26s @%8.1f  %8.1f us  grid %8s" % (name, (s - t0) / 1e3, (e - s) / 1e3, r['Grid_Size_X']))
+    print("%-26s @%8.1f  %8.1f us  ends %8.1f  grid %8s  queue %s" % (name, (s - t0) / 1e3, (e - s) / 1e3, (e - t0) / 1e3, r['Grid_Size_X'], r.get('Queue_Id', '?')))
 print("sum of kernel durations %.1f us, span %.1f us" % (tot / 1e3, (int(last[-1]['End_Timestamp']) - t0) / 1e3))

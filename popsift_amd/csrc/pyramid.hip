@@ -93,14 +93,20 @@ constexpr int blur_lds_floats()
     return (TH + 2 * HALO) * (TW + 2 * ((HALO + 3) & ~3));
 }
 
-template <int HALO, int MODE, int TH, int NT>
+/* LP lanes per 4x4 output block (NT = LP * TW / 4 * TH / 4 lanes per tile).  LP = 1 is the throughput shape described
+ * above.  LP > 1 (plane-to-plane, DoG not stored) is for the small octaves, whose launches are one round of workgroups
+ * and take as long as the instruction stream of ONE lane: the staged rows of the horizontal pass are dealt evenly to
+ * all NT / 32 half-waves and each block's four output rows of the vertical pass to LP lanes, so a lane executes about
+ * 1 / LP of the instructions (the values and their order per output do not change). */
+template <int HALO, int MODE, int TH, int NT, int LP = 1>
 __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, float* __restrict__ s_t)
 {
+    static_assert(LP == 1 || (MODE == 0 && (LP == 2 || LP == 4)), "LP > 1: plane-to-plane only");
+    constexpr int NB = NT / LP;           /* lanes that own a 4x4 block each   */
     constexpr int HP = (HALO + 3) & ~3;   /* left/right halo, padded to 16 B   */
     constexpr int SW = TW + 2 * HP;       /* LDS row pitch                     */
     constexpr int SR = TH + 2 * HALO;     /* rows staged                       */
     constexpr int NW = 1 + HP / 2;        /* H-pass window in 16 B chunks      */
-    constexpr int VW = 4 + 2 * HALO;      /* V-pass window rows                */
 
     const int tile = xcd_remap(block, a.tiles_x * a.tiles_y);
     const int tx0 = (tile % a.tiles_x) * TW;
@@ -333,7 +339,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
      * cx..cx+3 in BOTH passes: while it filters its four centre rows it keeps their source values
      * (the old plane, needed for the DoG) in registers, so the vertical pass does not read the old
      * plane again.  The 2*HALO halo rows are filtered afterwards, spread over the half-waves. */
-    constexpr int GROUPS = (TH / 4) / (NT / 32); /* 4-row groups per lane */
+    constexpr int GROUPS = (TH / 4) / (NB / 32); /* 4-row groups per lane */
     const int     lx = (tid & 31) * 4;           /* first output column of this lane */
     v4f           old[GROUPS][4];
     auto hrow = [&](int r) -> v4f {
@@ -365,28 +371,36 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
         *reinterpret_cast<v4f*>(&s_t[r * SW + HP + lx]) = out;
         return win[HP / 4]; /* the four source values under this lane's outputs */
     };
+    if (LP == 1) {
 #pragma unroll
-    for (int g = 0; g < GROUPS; g++) {
-        const int rg = (tid >> 5) + g * (NT / 32);
+        for (int g = 0; g < GROUPS; g++) {
+            const int rg = (tid >> 5) + g * (NT / 32);
 #pragma unroll
-        for (int j = 0; j < 4; j++) old[g][j] = hrow(HALO + 4 * rg + j);
+            for (int j = 0; j < 4; j++) old[g][j] = hrow(HALO + 4 * rg + j);
+        }
+        for (int hh = tid >> 5; hh < 2 * HALO; hh += NT / 32) (void)hrow(hh < HALO ? hh : TH + hh);
+    } else {
+        /* no DoG to form, so no lane needs the old values of "its" rows: every staged row to the next free half-wave */
+        for (int r = tid >> 5; r < SR; r += NT / 32) (void)hrow(r);
     }
-    for (int hh = tid >> 5; hh < 2 * HALO; hh += NT / 32) (void)hrow(hh < HALO ? hh : TH + hh);
     __syncthreads();
 
     /* ---- phase 3: vertical pass, 4 columns x 4 rows per lane, + DoG ------ */
     {
-        const int gx = tx0 + lx;
+        constexpr int NO = 4 / LP;                /* output rows of the block this lane computes */
+        constexpr int VWP = NO + 2 * HALO;        /* its window rows */
+        const int     bt = tid % NB, o0 = (tid / NB) * NO;
+        const int     gx = tx0 + lx;
 #pragma unroll
         for (int g = 0; g < GROUPS; g++) {
-            const int rg = (tid >> 5) + g * (NT / 32);
-            const int r0 = rg * 4; /* first output row (tile-relative) */
-            v4f       win[VW];
+            const int rg = (bt >> 5) + g * (NB / 32);
+            const int r0 = rg * 4; /* first output row of the block (tile-relative) */
+            v4f       win[VWP];
 #pragma unroll
-            for (int j = 0; j < VW; j++) win[j] = *reinterpret_cast<const v4f*>(&s_t[(r0 + j) * SW + HP + lx]);
+            for (int j = 0; j < VWP; j++) win[j] = *reinterpret_cast<const v4f*>(&s_t[(r0 + o0 + j) * SW + HP + lx]);
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int cpos = HALO + o;
+            for (int oo = 0; oo < NO; oo++) {
+                const int cpos = HALO + oo;
                 /* explicit 2-vectors: every FMA of the chain is a v_pk_fma_f32 (left to itself the compiler
                  * goes scalar on the rows whose x / z lanes also feed the next octave: 68 instead of 34) */
                 v2f alo = {0.0f, 0.0f}, ahi = {0.0f, 0.0f};
@@ -404,15 +418,15 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                     ahi = __builtin_elementwise_fma(win[cpos].hi, g0, ahi);
                 }
                 const v4f acc = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3);
-                const int gy = ty0 + r0 + o;
+                const int gy = ty0 + r0 + o0 + oo;
                 if (gx < w && gy < h) {
                     /* rows are padded to 64 floats, so a 16 B store at gx < w stays inside the row */
                     /* the Gaussian plane is the next level's input (keep it cached); the DoG plane is not touched again
                      * before the detection kernel: a non-temporal store keeps it from evicting the plane
                      * (measured: level launches -4 %, detection -7 %; non-temporal for both: levels +20 %) */
                     *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
-                    if (MODE == 0 && a.dog)
-                        __builtin_nontemporal_store(acc - old[g][o], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
+                    if (LP == 1 && MODE == 0 && a.dog)
+                        __builtin_nontemporal_store(acc - old[g][oo], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
                     /* the next octave's level 0 takes pixel (2x, 2y): its width is ceil(w / 2), so 2x <= w - 1 always
                      * and the reference's min(2x, w - 1) never clamps.  gx is a multiple of 4. */
                     if (MODE == 0 && a.next0 && (gy & 1) == 0) {
@@ -443,15 +457,23 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
  * octaves on separate streams for the same reason; one stream and merged launches do it here without the extra
  * streams, which cost throughput when 16 contexts are in flight).
  */
-template <int HALO>
-__global__ __launch_bounds__(256) void k_blur_duo(BlurArgs a, BlurArgs b)
+template <int HALO, int LP>
+__global__ __launch_bounds__(256 * LP) void k_blur_duo(BlurArgs a, BlurArgs b)
 {
     __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, 32>()];
     const int na = a.tiles_x * a.tiles_y;
     if ((int)blockIdx.x < na)
-        blur_tile_body<HALO, 0, 32, 256>(a, blockIdx.x, s_t);
+        blur_tile_body<HALO, 0, 32, 256 * LP, LP>(a, blockIdx.x, s_t);
     else
-        blur_tile_body<HALO, 0, 32, 256>(b, blockIdx.x - na, s_t);
+        blur_tile_body<HALO, 0, 32, 256 * LP, LP>(b, blockIdx.x - na, s_t);
+}
+
+/* one small plane, 32-row tiles, LP lanes per block */
+template <int HALO, int LP>
+__global__ __launch_bounds__(256 * LP) void k_blur_small(BlurArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, 32>()];
+    blur_tile_body<HALO, 0, 32, 256 * LP, LP>(a, blockIdx.x, s_t);
 }
 
 /* get_by_2_pick_every_second (s_pyramid_build.cu:50-71) */
@@ -504,16 +526,26 @@ int blur_tile_h(int w, int h)
     return tiles64 >= min_tiles ? 64 : 32;
 }
 
-/* both planes with 32-row tiles and plane-to-plane filtering (mode 0) */
+/* lanes per 4x4 block for small planes: 1 / 2 / 4 -> pyramid stage of a 1080p image 291 / 295 / 275 us */
+constexpr int BLUR_SMALL_LP = 4;
+/* a plane whose level launch is one round of workgroups (at most one 128 x 32 tile per CU): latency, not throughput */
+bool blur_is_small(int w, int h) { return (long)((w + TW - 1) / TW) * ((h + 31) / 32) <= 256; }
+
+/* both planes with 32-row tiles and plane-to-plane filtering (mode 0); more lanes per tile when both planes are small
+ * and no DoG is stored */
 hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, hipStream_t s)
 {
     const int halo = std::max(span_a, span_b) - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    const dim3 grid(a.tiles_x * a.tiles_y + b.tiles_x * b.tiles_y), block(256);
-#define PS_CASE(H)                                                      \
-    if (halo <= H) {                                                    \
-        hipLaunchKernelGGL((k_blur_duo<H>), grid, block, 0, s, a, b);   \
-        return hipGetLastError();                                       \
+    const bool small = !a.dog && !b.dog && blur_is_small(a.w, a.h) && blur_is_small(b.w, b.h) && halo <= 16;
+    const dim3 grid(a.tiles_x * a.tiles_y + b.tiles_x * b.tiles_y), block(small ? 256 * BLUR_SMALL_LP : 256);
+#define PS_CASE(H)                                                                     \
+    if (halo <= H) {                                                                   \
+        if (small)                                                                     \
+            hipLaunchKernelGGL((k_blur_duo<H, BLUR_SMALL_LP>), grid, block, 0, s, a, b); \
+        else                                                                           \
+            hipLaunchKernelGGL((k_blur_duo<H, 1>), grid, block, 0, s, a, b);            \
+        return hipGetLastError();                                                      \
     }
     PS_CASE(4)
     PS_CASE(5)
@@ -523,8 +555,35 @@ hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int
     PS_CASE(10)
     PS_CASE(13)
     PS_CASE(16)
+#undef PS_CASE
+#define PS_CASE(H)                                                        \
+    if (halo <= H) {                                                      \
+        hipLaunchKernelGGL((k_blur_duo<H, 1>), grid, block, 0, s, a, b);   \
+        return hipGetLastError();                                         \
+    }
     PS_CASE(22)
     PS_CASE(30)
+#undef PS_CASE
+    return hipErrorInvalidValue;
+}
+
+/* one small plane (blur_is_small, 32-row tiles, plane-to-plane, no stored DoG, at most 33 taps) */
+static hipError_t launch_blur_small(const BlurArgs& a, int halo, hipStream_t s)
+{
+    const dim3 grid(a.tiles_x * a.tiles_y), block(256 * BLUR_SMALL_LP);
+#define PS_CASE(H)                                                                  \
+    if (halo <= H) {                                                                \
+        hipLaunchKernelGGL((k_blur_small<H, BLUR_SMALL_LP>), grid, block, 0, s, a);  \
+        return hipGetLastError();                                                   \
+    }
+    PS_CASE(4)
+    PS_CASE(5)
+    PS_CASE(6)
+    PS_CASE(7)
+    PS_CASE(8)
+    PS_CASE(10)
+    PS_CASE(13)
+    PS_CASE(16)
 #undef PS_CASE
     return hipErrorInvalidValue;
 }
@@ -533,6 +592,7 @@ hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStr
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
+    if (mode == 0 && tile_h == 32 && !a.dog && halo <= 16 && blur_is_small(a.w, a.h)) return launch_blur_small(a, halo, s);
     constexpr int nt64 = 512;
     /* 512 lanes per 64-row tile halve the serial work per wave at the same LDS footprint (measured
      * -12 % per launch); the 27-tap instance needs ~150 VGPRs for its vertical window and is better

@@ -90,6 +90,7 @@ struct popsift_hip_ctx {
     size_t   iext_cap = 0, iext2_cap = 0, extrec_cap = 0, feats_cap = 0;
     int*     d_map = nullptr;
     float2*  d_rot = nullptr; /* (cos, sin) of every descriptor's orientation, correctly rounded (k_scan_apply) */
+    DescRec* d_drec = nullptr; /* per-descriptor constants of the loop descriptor (k_scan_apply -> k_descriptor) */
     float*   d_desc = nullptr;
     int      desc_cap = 0;
     /* second result slab (popsift_hip_fetch_begin): the download of image i reads one slab on copy_stream while the
@@ -261,13 +262,16 @@ int ensure_desc_cap(popsift_hip_ctx* c, int need)
     if (c->d_desc) HIP_TRY(c, hipFree(c->d_desc));
     if (c->d_map) HIP_TRY(c, hipFree(c->d_map));
     if (c->d_rot) HIP_TRY(c, hipFree(c->d_rot));
+    if (c->d_drec) HIP_TRY(c, hipFree(c->d_drec));
     c->d_desc = nullptr;
     c->d_map = nullptr;
     c->d_rot = nullptr;
+    c->d_drec = nullptr;
     c->desc_cap = 0;
     HIP_TRY(c, ctx_malloc(c, (void**)&c->d_desc, (size_t)need * 128 * sizeof(float)));
     HIP_TRY(c, ctx_malloc(c, (void**)&c->d_map, (size_t)need * sizeof(int)));
     HIP_TRY(c, ctx_malloc(c, (void**)&c->d_rot, (size_t)need * sizeof(float2)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_drec, (size_t)need * sizeof(DescRec)));
     c->desc_cap = need;
     return 0;
 }
@@ -541,10 +545,10 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_SCAN));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
     HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->d_ext, c->d_partial,
-                           std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_feats, c->desc_cap, c->stream));
+                           std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_drec, c->d_feats, c->desc_cap, c->stream));
     SYNC_CHK(c, "k_scan_local / k_scan_apply");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DESCRIPTOR));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_desc, c->desc_cap, c->kp_waves,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_drec, c->d_desc, c->desc_cap, c->kp_waves,
                                   c->stream));
     SYNC_CHK(c, "descriptor kernel");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_COUNT));
@@ -902,6 +906,7 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
     if (c->d_feats) (void)hipFree(c->d_feats);
     if (c->d_map) (void)hipFree(c->d_map);
     if (c->d_rot) (void)hipFree(c->d_rot);
+    if (c->d_drec) (void)hipFree(c->d_drec);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->alt_feats) (void)hipFree(c->alt_feats);
     if (c->alt_desc) (void)hipFree(c->alt_desc);

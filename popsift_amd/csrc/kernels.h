@@ -53,10 +53,11 @@ hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const Sif
 int        scan_chunk(); /* extrema per k_scan_apply workgroup */
 int        scan_partials_per_chunk(); /* partial sums k_scan_local leaves per scan_chunk() extrema */
 hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
-                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot,
+                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot, DescRec* drec,
                        popsift_hip_feature* feats, int desc_cap, hipStream_t s);
 hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, const Ext* ext,
-                              const int* map, const float2* rot, float* desc, int desc_cap, int blocks, hipStream_t s);
+                              const int* map, const float2* rot, const DescRec* drec, float* desc, int desc_cap, int blocks,
+                              hipStream_t s);
 
 /* filter.hip: grid filter between refinement and orientation (s_filtergrid.cu:109-322) */
 bool       filter_supported(int n_oct, int max_extrema, int grid_size);

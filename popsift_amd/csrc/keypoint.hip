@@ -455,6 +455,44 @@ __device__ __forceinline__ int ori_peaks_quad(const float* __restrict__ hsrc, in
     return angles;
 }
 
+/* The per-descriptor constants of the loop descriptor (k_descriptor), computed where one lane serves one extremum.
+ * fbits: each cell word packs two 32-bit fixed-point sums (low = share of orientation bin b, high = share of bin b+1
+ * from samples whose lower bin is b), so ONE 64-bit LDS atomic per cell serves both bins of a sample; the scale 2^fbits
+ * keeps the worst-case low sum below 2^32 (no carry into the high half): a sample weighs <= 361 (|gradient| of a
+ * 0..255 plane, unit window weights) and a cell sees at most (2.83*SBP+1)^2 pixels. */
+__device__ __forceinline__ DescRec make_desc_rec(const PyrDesc* __restrict__ pdp, const Ext& e, float angle, float cos_t, float sin_t)
+{
+    DescRec        r;
+    const OctDesc* od = &pdp->o[e.octave];
+    const int      lvl = min(max(e.lpos, 0), pdp->L - 1);
+    const long long off = od->data_off + lvl * od->plane_stride;
+    const float    x = e.xpos, y = e.ypos;
+    const float    SBP = fabsf(DESC_MAGNIFY * e.sigma);
+    const float    cell_px = (2.83f * SBP + 1.0f) * (2.83f * SBP + 1.0f);
+    const int      fbits = min(max(31 - (int)ceilf(log2f(361.0f * cell_px)), 2), 20);
+    const float    csbp = cos_t * SBP, ssbp = sin_t * SBP;
+    const float    bsz = fabsf(csbp) + fabsf(ssbp);
+    /* union of the 16 cell boxes: cell centres reach 1.5 * bsz, each box adds bsz */
+    const float    ext_r = 2.5f * bsz;
+    const int      xmin = max(1, (int)floorf(x - ext_r));
+    const int      ymin = max(1, (int)floorf(y - ext_r));
+    const int      xmax = min(od->w - 2, (int)floorf(x + ext_r) + 1);
+    const int      ymax = min(od->h - 2, (int)floorf(y + ext_r) + 1);
+    r.x = x;
+    r.y = y;
+    r.crsbp = cos_t / SBP;
+    r.srsbp = sin_t / SBP;
+    r.ang_bins = angle * (4.0f / F_PI);
+    r.fscale = scalbnf(1.0f, fbits);
+    r.xymin = ((unsigned int)xmin & 0xffffu) | ((unsigned int)ymin << 16);
+    r.xymax = ((unsigned int)xmax & 0xffffu) | ((unsigned int)ymax << 16);
+    r.off_lo = (unsigned int)((unsigned long long)off & 0xffffffffull);
+    r.off_hi = (unsigned int)((unsigned long long)off >> 32);
+    r.misc = (unsigned int)od->pitch | ((unsigned int)fbits << 16) | ((SBP != 0.0f) ? (1u << 24) : 0u);
+    r.pad = 0u;
+    return r;
+}
+
 /* ------------------------------------------------------------------- scan */
 
 /*
@@ -545,8 +583,8 @@ __global__ __launch_bounds__(SCAN_LT) void k_scan_local(const PyrDesc* __restric
 __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc,
                                                     Counters* __restrict__ ct, Ext* __restrict__ ext,
                                                     const int* __restrict__ partial, int* __restrict__ map,
-                                                    float2* __restrict__ rot, popsift_hip_feature* __restrict__ feats,
-                                                    int desc_cap)
+                                                    float2* __restrict__ rot, DescRec* __restrict__ drec,
+                                                    popsift_hip_feature* __restrict__ feats, int desc_cap)
 {
     __shared__ int s_red[4];
     __shared__ int s_ps[PS_MAX_OCT + 1];
@@ -616,6 +654,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
                     float sn, cs;
                     sincos_cr(e.orientation[q], sn, cs);
                     rot[idx + q] = make_float2(cs, sn);
+                    if (drec) drec[idx + q] = make_desc_rec(pdp, e, e.orientation[q], cs, sn);
                 }
             }
             feats[g] = f;
@@ -690,8 +729,7 @@ constexpr int DESC_GL = 64 / DESC_GROUPS; /* lanes per group */
 
 __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
                                                        const float* __restrict__ arena, SiftConsts sc,
-                                                       Counters* __restrict__ ct, const Ext* __restrict__ ext,
-                                                       const int* __restrict__ map, const float2* __restrict__ rot,
+                                                       Counters* __restrict__ ct, const DescRec* __restrict__ drec,
                                                        float* __restrict__ desc, int desc_cap)
 {
     __shared__ __attribute__((aligned(1024))) fix64 s_hist[KP_NW][DESC_COPIES * 128];
@@ -703,48 +741,30 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
     char*         hbase = (char*)(hall + cpy * 128);
     unsigned int* rinfo = s_row[wave];
     const int     total = min(ct->ori_total, desc_cap);
-    const int     L = pdp->L;
+    
 
     for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
         const int d = sl.index();
         if (d >= total) continue;
-        const Ext*     e = ext + map[d];
-        const float    x = uniformf(e->xpos), y = uniformf(e->ypos), sigma = uniformf(e->sigma);
-        const OctDesc* od = &pdp->o[e->octave];
-        /* everything about the descriptor is wave-uniform: say so, and the plane base, the pitch and the bounds live in
-         * scalar registers (the taps become scalar-base + 32-bit-offset loads) */
-        const int      width = uniform(od->w), height = uniform(od->h), pitch = uniform(od->pitch);
-        const int      lvl = min(max(e->lpos, 0), L - 1);
-        const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
+        /* everything about the descriptor is wave-uniform and was worked out by k_scan_apply (DescRec): three 16-byte
+         * loads of one address, moved to scalar registers (the taps become scalar-base + 32-bit-offset loads) */
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4*          rp = reinterpret_cast<const u4*>(drec + d);
+        const u4           q0 = rp[0], q1 = rp[1], q2 = rp[2];
+        const float        x = uniformf(__uint_as_float(q0.x)), y = uniformf(__uint_as_float(q0.y));
+        const float        crsbp = uniformf(__uint_as_float(q0.z)), srsbp = uniformf(__uint_as_float(q0.w));
+        const float        ang_bins = uniformf(__uint_as_float(q1.x)), fscale = uniformf(__uint_as_float(q1.y));
+        const int          pmin = uniform((int)q1.z), pmax = uniform((int)q1.w);
+        const unsigned int misc = (unsigned int)uniform((int)q2.z);
+        const int          pitch = (int)(misc & 0xffffu), fbits = (int)((misc >> 16) & 0xffu);
+        const float*       layer = arena + uniform64((long long)(((unsigned long long)q2.y << 32) | q2.x));
 
 #pragma unroll
         for (int k = 0; k < 2 * DESC_COPIES; k++) hall[lane + 64 * k] = 0ull;
 
-        const float SBP = fabsf(DESC_MAGNIFY * sigma);
-        /* Each cell word packs two 32-bit fixed-point sums: low = share of orientation bin b, high =
-         * share of bin b+1 coming from samples whose lower bin is b, so ONE 64-bit LDS atomic per cell
-         * serves both bins of a sample.  The scale 2^fbits keeps the worst-case low sum below 2^32
-         * (no carry into the high half): a sample weighs <= 361 (|gradient| of a 0..255 plane, unit
-         * window weights) and a cell sees at most (2.83*SBP+1)^2 pixels. */
-        const float cell_px = (2.83f * SBP + 1.0f) * (2.83f * SBP + 1.0f);
-        const int   fbits = min(max(31 - (int)ceilf(log2f(361.0f * cell_px)), 2), 20);
-        const float fscale = uniformf(scalbnf(1.0f, fbits));
-        if (SBP != 0.0f) {
-            float sin_t, cos_t;
-            cos_t = uniformf(rot[d].x);
-            sin_t = uniformf(rot[d].y);
-            /* the orientation this descriptor belongs to, in units of one descriptor bin (pi / 4) */
-            const int   ko = min(max(d - e->idx_ori, 0), POPSIFT_HIP_ORI_MAX - 1);
-            const float ang_bins = uniformf(e->orientation[ko] * (4.0f / F_PI));
-            const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
-            const float crsbp = cos_t / SBP, srsbp = sin_t / SBP;
-            const float bsz = fabsf(csbp) + fabsf(ssbp);
-            /* union of the 16 cell boxes: cell centres reach 1.5 * bsz, each box adds bsz */
-            const float ext_r = 2.5f * bsz;
-            const int   xmin = max(1, (int)floorf(x - ext_r));
-            const int   ymin = max(1, (int)floorf(y - ext_r));
-            const int   xmax = min(width - 2, (int)floorf(x + ext_r) + 1);
-            const int   ymax = min(height - 2, (int)floorf(y + ext_r) + 1);
+        if (misc & (1u << 24)) { /* DESC_MAGNIFY * sigma != 0 */
+            const int   xmin = (int)(short)(pmin & 0xffff), ymin = pmin >> 16;
+            const int   xmax = (int)(short)(pmax & 0xffff), ymax = pmax >> 16;
             const int   wx = xmax - xmin + 1;
             const int   hy = ymax - ymin + 1;
             const bool  spans = (hy <= DESC_MAXROWS && wx < 4096);
@@ -802,7 +822,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
             wave_lds_sync();
 
             const int   loops = spans ? T : ((wx > 0 && hy > 0) ? wx * hy : 0);
-            const float inv_wx = 1.0f / (float)max(wx, 1);
+            float       inv_wx = 0.0f; /* bounding-box scan only (a division) */
+            if (!spans) inv_wx = 1.0f / (float)max(wx, 1);
             /* every lane group takes its own part of the list */
             const int   quarter = (loops + DESC_GROUPS - 1) / DESC_GROUPS;
             const int   ibeg = grp * quarter, iend = min(ibeg + quarter, loops);
@@ -810,19 +831,24 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
             int          row = 0;
             unsigned int cur = 0;
             if (spans && loops > 0) {
-                /* the row that holds this lane's first sample: largest r with start(r) <= i0 (empty rows share the
-                 * start of their successor, so that row is not empty) */
-                const int i0 = min(ibeg + sub, loops - 1);
-                int       lo = 0, hi = hy - 1;
+                /* The row that holds the first sample of this lane's GROUP (coord() walks on from there to the lane's
+                 * own): the one non-empty row r with start(r) <= key < start(r + 1).  Every row looks at its own
+                 * interval, a ballot per group finds it -- two LDS reads instead of the seven dependent ones of a
+                 * binary search per lane. */
+                int grow = 0;
+                for (int rb = 0; rb < hy; rb += 64) {
+                    const int  r = rb + lane;
+                    const bool in = r < hy;
+                    const int  st = in ? (int)(rinfo[r] & 0xfffffu) : 0x7fffffff;
+                    const int  en = in ? (int)(rinfo[r + 1] & 0xfffffu) : 0x7fffffff;
 #pragma unroll
-                for (int it = 0; it < 7; it++) { /* DESC_MAXROWS = 2^7 */
-                    const int mid = (lo + hi + 1) >> 1;
-                    if ((int)(rinfo[mid] & 0xfffffu) <= i0)
-                        lo = mid;
-                    else
-                        hi = mid - 1;
+                    for (int g = 0; g < DESC_GROUPS; g++) {
+                        const int                key = min(g * quarter, loops - 1);
+                        const unsigned long long m = __ballot(st <= key && key < en);
+                        if (m != 0ull && grp == g) grow = rb + __ffsll((long long)m) - 1;
+                    }
                 }
-                row = lo;
+                row = grow;
                 cur = rinfo[row];
             }
 
@@ -1305,12 +1331,13 @@ hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftC
 }
 
 hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
-                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot,
+                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot, DescRec* drec,
                        popsift_hip_feature* feats, int desc_cap, hipStream_t s)
 {
     /* n_chunks is the capacity of the lists; a 1080p image fills ~300 chunks */
     hipLaunchKernelGGL(k_scan_local, dim3(std::min(n_chunks * SCAN_SUB, 512 * SCAN_SUB)), dim3(SCAN_LT), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
-    hipLaunchKernelGGL(k_scan_apply, dim3(std::min(n_chunks, 1024)), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot, feats, desc_cap);
+    hipLaunchKernelGGL(k_scan_apply, dim3(std::min(n_chunks, 1024)), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot,
+                       sc.desc_mode == POPSIFT_HIP_DESC_LOOP ? drec : nullptr, feats, desc_cap);
     return hipGetLastError();
 }
 
@@ -1318,8 +1345,8 @@ int scan_chunk() { return SCAN_CHUNK; }
 int scan_partials_per_chunk() { return SCAN_SUB; }
 
 hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, Counters* ct,
-                              const Ext* ext, const int* map, const float2* rot, float* desc, int desc_cap, int blocks,
-                              hipStream_t s)
+                              const Ext* ext, const int* map, const float2* rot, const DescRec* drec, float* desc, int desc_cap,
+                              int blocks, hipStream_t s)
 {
     /* IGrid (s_desc_igrid.cu:20-83) evaluates the same 40 x 40 point lattice with the same weights as NoTile,
      * cell by cell (each point up to four times); the two differ only in summation order (6e-7 relative in the
@@ -1331,7 +1358,7 @@ hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftC
     else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
         hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
     else
-        hipLaunchKernelGGL(k_descriptor, dim3(blocks / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor, dim3(blocks / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, drec, desc, desc_cap);
     return hipGetLastError();
 }
 

@@ -67,6 +67,22 @@ struct Ext {
     float orientation[POPSIFT_HIP_ORI_MAX];
 };
 
+/* Everything about one (extremum, orientation) that the loop-descriptor kernel would otherwise derive, wave-uniformly and
+ * once per descriptor, from the extremum, its octave and its rotation: written by k_scan_apply with one LANE per extremum
+ * (same expressions, same values), read by k_descriptor as three 16-byte loads.  48 bytes. */
+struct DescRec {
+    float        x, y;         /* position in the octave */
+    float        crsbp, srsbp; /* cos, sin of the orientation / (DESC_MAGNIFY * sigma): pixel -> cell units */
+    float        ang_bins;     /* orientation in descriptor bins (pi / 4) */
+    float        fscale;       /* 2^fbits: fixed-point scale of the histogram */
+    unsigned int xymin, xymax; /* patch bounding box, two signed 16-bit halves each (x low, y high) */
+    unsigned int off_lo, off_hi; /* offset of the Gaussian plane in the arena, in floats (64 bits) */
+    unsigned int misc;         /* pitch (16 bits) | fbits << 16 | valid << 24 */
+    unsigned int pad;
+};
+
+static_assert(sizeof(DescRec) == 48, "three 16-byte loads");
+
 /* sift_pyramid.h:22-37 ExtremaCounters, device resident */
 struct Counters {
     int ext_ct[PS_MAX_OCT];

@@ -316,13 +316,16 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
             if (sq_dist <= sq_thres) {
                 const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
                 const float weight = grad * __expf(sq_dist * factor);
-                /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the reference's quotient only when
-                 * the result is within an ulp of k + 0.5.
+                /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the oracle's quotient only when the result is
+                 * within an ulp of k + 0.5 -- which the near-edge path below takes care of.
                  * The bin is a HARD decision, so the angle needs libm-grade accuracy -- but only when it lies next
                  * to a bin edge: the cheap atan2 (error < 5e-7 rad = 3e-6 bins) decides every sample farther than
                  * 1e-4 bins from an edge, identically to the accurate one, which the others (1 in 5000) then take. */
                 float       fb = (fast_atan2(gdy, gdx) + F_PI) * ((float)PS_ORI_NBINS / F_PI2);
-                if (fabsf(fb - floorf(fb) - 0.5f) < 1e-4f) fb = (atan2_acc(gdy, gdx) + F_PI) * ((float)PS_ORI_NBINS / F_PI2);
+                /* next to an edge the value is formed exactly as the oracle forms it (product, then IEEE quotient): gradients
+                 * of exactly 45 degrees -- frequent in level 0 of the up-scaled octave -- sit ON the edge 22.5, 31.5, ...,
+                 * where the two formulas round to different sides */
+                if (fabsf(fb - floorf(fb) - 0.5f) < 1e-4f) fb = (float)PS_ORI_NBINS * (atan2_acc(gdy, gdx) + F_PI) / F_PI2;
                 int         bidx = (int)roundf(fb);
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
                 if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));

@@ -42,6 +42,11 @@ CASES = [
     ("iloop_descriptor", dict(desc_mode=1), (33, 200, 150)),
     ("iloop_descriptor_vlfeat_classic", dict(desc_mode=1, sift_mode=2, norm_mode=1), (34, 160, 120)),
     ("notile_descriptor_opencv_classic", dict(desc_mode=4, sift_mode=1, norm_mode=1, norm_multi=9), (31, 200, 150)),
+    # six levels from sigma 1.008: ~2 % of the extrema refine to level 0 of the up-scaled octave, whose bilinear samples
+    # make gradients of exactly 45 degrees -- ON the orientation-bin edges 22.5, 31.5, ... (found by tools/fuzz_parity.py
+    # 250 777, case 243: 55 of 37 871 descriptors off while the near-edge path formed the bin differently from the oracle)
+    ("levels6_sigma1_level0_extrema", dict(levels=6, sigma=1.0083268880844116, sift_mode=2, octaves=5, edge_limit=7.336590766906738,
+                                           threshold=0.026724137365818024), (1243, 630, 216)),
 ]
 
 

@@ -1,5 +1,5 @@
 """Re-run ONE case of tools/fuzz_parity.py (same generator state) and say where its descriptors differ.
-python3 tools/fuzz_one.py <seed> <case>   (GPU box; POPSIFT_HIP_LIB selects another build)"""
+python3 tools/fuzz_one.py <seed> <case> [max_w max_h]   (GPU box; POPSIFT_HIP_LIB selects another build)"""
 import os
 import sys
 
@@ -17,7 +17,7 @@ O.build()
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
 for case in range(want + 1):
-    kw, img = fuzz_cases.random_case(rng, case)
+    kw, img = fuzz_cases.random_case(rng, case, *((int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else ()))
 print(kw, img.shape, img.dtype)
 print(fuzz_cases.check_case(O, hip, kw, img))
 orc = O.Oracle(O.default_params(**kw), threads=16).run(img)

@@ -1,5 +1,6 @@
 """Randomised differential test: oracle vs HIP on random sizes / parameters (tests/fuzz_cases.py; a fixed 60-case
-slice of it is tests/test_gpu_fuzz.py).  Open-ended here: python3 tools/fuzz_parity.py [n_cases] [seed], on the GPU box."""
+slice of it is tests/test_gpu_fuzz.py).  Open-ended here: python3 tools/fuzz_parity.py [n_cases] [seed] [max_w max_h], on the
+GPU box."""
 import os
 import sys
 
@@ -15,9 +16,10 @@ from popsift_amd import _capi as hip
 O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+SIZE = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else ()
 bad = 0
 for case in range(n_cases):
-    kw, img = fuzz_cases.random_case(rng, case)
+    kw, img = fuzz_cases.random_case(rng, case, *SIZE)
     ok, msg = fuzz_cases.check_case(O, hip, kw, img)
     bad += 0 if ok else 1
     print("%s case %2d %dx%d %s %s" % ("ok  " if ok else "FAIL", case, img.shape[1], img.shape[0], kw, msg), flush=True)

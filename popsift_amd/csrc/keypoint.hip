@@ -69,6 +69,20 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+/* Inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15
+ * and row_bcast:31 carry the row totals across), register to register -- no LDS round trips as with six shuffles. */
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); /* row_shr:1, out-of-row lanes read 0 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+
+
 /* a value every lane of the wave holds identically, moved to scalar registers */
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -564,12 +578,7 @@ __global__ __launch_bounds__(SCAN_LT) void k_scan_local(const PyrDesc* __restric
         for (int q = 0; q < POPSIFT_HIP_ORI_MAX; q++) e.orientation[q] = 0.0f;
     const int self = (valid && j == 0) ? e.num_ori : 0;
 
-    int incl = self;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const int v = __shfl_up(incl, s);
-        if (lane >= s) incl += v;
-    }
+    const int incl = wave_incl_scan(self);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     int woff = 0;
@@ -810,12 +819,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                         len = ok ? max(jhi - jlo + 1, 0) : 0;
                         if (len == 0) jlo = xmin;
                     }
-                    int incl = len;
-#pragma unroll
-                    for (int s = 1; s < 64; s <<= 1) {
-                        const int v = __shfl_up(incl, s);
-                        if (lane >= s) incl += v;
-                    }
+                    const int incl = wave_incl_scan(len);
                     if (r < hy) rinfo[r] = (unsigned int)(carry + incl - len) | ((unsigned int)(jlo - xmin) << 20);
                     carry += __shfl(incl, 63);
                 }

@@ -310,24 +310,12 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
             yy = row + ymin;
             xx = i - __mul24(row, wx) + xmin;
         };
-        int   xn = xmin, yn = ymin;
-        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
-        const Taps taps(layer, pitch);
-        if (loops > 0) {
-            coord(min(lane, loops - 1), xn, yn);
-            taps.load(__mul24(yn, pitch) + xn, g0, g1, g2, g3);
-        }
-        for (int i = lane; i < loops; i += 64) {
-            const int   xx = xn, yy = yn;
-            const float gdx = g0 - g1, gdy = g2 - g3;
-            {
-                coord(min(i + 64, loops - 1), xn, yn);
-                taps.load(__mul24(yn, pitch) + xn, g0, g1, g2, g3);
-            }
+        /* one sample: pixel (xx, yy) with gradient (gdx, gdy) -> at most one fixed-point LDS atomic */
+        auto bin = [&](int xx, int yy, float gdx, float gdy, bool live) {
             const float dx = xx - x;
             const float dy = yy - y;
             const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
-            if (sq_dist <= sq_thres) {
+            if (live && sq_dist <= sq_thres) {
                 const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
                 const float weight = grad * __expf(sq_dist * factor);
                 /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the oracle's quotient only when the result is
@@ -344,6 +332,23 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
                 if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));
             }
+        };
+        /* two register sets take turns as "being binned" and "in flight", as in k_descriptor (unrolled by two, so no
+         * value is copied from one role to the other) */
+        int   xa = xmin, ya = ymin, xb = xmin, yb = ymin;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+        const Taps taps(layer, pitch);
+        if (loops > 0) {
+            coord(min(lane, loops - 1), xa, ya);
+            taps.load(__mul24(ya, pitch) + xa, a0, a1, a2, a3);
+        }
+        for (int i = lane; i < loops; i += 128) {
+            coord(min(i + 64, loops - 1), xb, yb);
+            taps.load(__mul24(yb, pitch) + xb, b0, b1, b2, b3);
+            bin(xa, ya, a0 - a1, a2 - a3, true);
+            coord(min(i + 128, loops - 1), xa, ya);
+            taps.load(__mul24(ya, pitch) + xa, a0, a1, a2, a3);
+            bin(xb, yb, b0 - b1, b2 - b3, i + 64 < loops);
         }
         wave_lds_sync();
 

@@ -302,7 +302,9 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         const int   wx = xmax - xmin + 1;
         const int   hy = ymax - ymin + 1;
         const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
-        const float inv_wx = 1.0f / (float)max(wx, 1);
+        /* row of flat index i = (int)((i + 0.5) / wx): the half keeps the quotient at least 0.5 / wx away from an integer,
+         * far more than the ulp by which v_rcp may miss 1 / wx, so the approximate reciprocal gives the exact row */
+        const float inv_wx = __builtin_amdgcn_rcpf((float)max(wx, 1));
 
         /* software pipeline as in k_descriptor: request the taps of sample i+64 while binning sample i */
         auto coord = [&](int i, int& xx, int& yy) {

@@ -42,26 +42,6 @@ typedef unsigned long long fix64;
 __device__ __forceinline__ fix64 to_fix(float w) { return (fix64)(unsigned int)(w * 1048576.0f); }
 __device__ __forceinline__ float from_fix(fix64 v) { return (float)((double)v * (1.0 / 1048576.0)); }
 
-/* atan2 for the descriptor's *soft* orientation binning (continuous in theta, so ~3e-7 rad
- * of error is immaterial; the reference itself uses fast intrinsics there, s_desc_loop.cu:48,97).
- * Cephes-style: reduce to |t| <= tan(pi/8), odd degree-9 polynomial, v_rcp instead of IEEE division. */
-__device__ __forceinline__ float fast_atan2(float y, float x)
-{
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float       a = mn * __builtin_amdgcn_rcpf(mx);
-    a = (mx == 0.0f) ? 0.0f : a;
-    const bool  big = a > 0.41421356f;
-    const float t = big ? (a - 1.0f) * __builtin_amdgcn_rcpf(a + 1.0f) : a;
-    const float s = t * t;
-    const float p = fmaf(fmaf(fmaf(8.05374449538e-2f, s, -1.38776856032e-1f), s, 1.99777106478e-1f), s,
-                         -3.33329491539e-1f);
-    float       r = fmaf(t * s, p, t);
-    r = big ? r + 0.785398163f : r;
-    r = (ay > ax) ? 1.570796327f - r : r;
-    r = (x < 0.0f) ? 3.141592654f - r : r;
-    return (y < 0.0f) ? -r : r;
-}
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -246,6 +226,28 @@ __device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
     c = (float)(((n + 1) & 2) ? -cd : cd);
 }
 
+/* atan2(y, x) * 4/pi in (-4, 4]: octant reduction + odd degree-11 minimax polynomial of
+ * atan(r) * 4/pi on [0, 1] (max error 2.2e-6 bins = 1.7e-6 rad, fitted offline), v_rcp instead of
+ * a division.  Only used for the descriptor's SOFT orientation binning, which is continuous in
+ * the angle (the reference uses fast intrinsics there too, s_desc_loop.cu:48,97). */
+__device__ __forceinline__ float atan2_bins(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float       r = mn * __builtin_amdgcn_rcpf(mx);
+    r = (mx == 0.0f) ? 0.0f : r;
+    const float s = r * r;
+    float       p = fmaf(-0.01492126751691103f, s, 0.06703268736600876f);
+    p = fmaf(p, s, -0.14823880791664124f);
+    p = fmaf(p, s, 0.24642325937747955f);
+    p = fmaf(p, s, -0.42350852489471436f);
+    p = fmaf(p, s, 1.2732105255126953f);
+    float t = p * r;
+    t = (ay > ax) ? 2.0f - t : t;
+    t = (x < 0.0f) ? 4.0f - t : t;
+    return (y < 0.0f) ? -t : t;
+}
+
 #ifndef KP_NW
 #define KP_NW 1 /* waves per workgroup of k_orientation / k_descriptor: the waves are independent (one keypoint each) */
 #endif
@@ -320,12 +322,11 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
             if (live && sq_dist <= sq_thres) {
                 const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
                 const float weight = grad * __expf(sq_dist * factor);
-                /* x * (36 / 2pi) instead of 36 * x / 2pi: differs from the oracle's quotient only when the result is
-                 * within an ulp of k + 0.5 -- which the near-edge path below takes care of.
-                 * The bin is a HARD decision, so the angle needs libm-grade accuracy -- but only when it lies next
-                 * to a bin edge: the cheap atan2 (error < 5e-7 rad = 3e-6 bins) decides every sample farther than
-                 * 1e-4 bins from an edge, identically to the accurate one, which the others (1 in 5000) then take. */
-                float       fb = (fast_atan2(gdy, gdx) + F_PI) * ((float)PS_ORI_NBINS / F_PI2);
+                /* The bin is a HARD decision, so the angle needs libm-grade accuracy -- but only when it lies next to a
+                 * bin edge: the cheap atan2 (the descriptor's one-reciprocal degree-11 polynomial in units of pi / 4:
+                 * error < 1.7e-6 rad = 1e-5 of these bins) decides every sample farther than 1e-4 bins from an edge
+                 * identically to the accurate one, which the others (1 in 5000) then take. */
+                float       fb = (atan2_bins(gdy, gdx) + 4.0f) * ((float)PS_ORI_NBINS / 8.0f);
                 /* next to an edge the value is formed exactly as the oracle forms it (product, then IEEE quotient): gradients
                  * of exactly 45 degrees -- frequent in level 0 of the up-scaled octave -- sit ON the edge 22.5, 31.5, ...,
                  * where the two formulas round to different sides */
@@ -698,28 +699,6 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
 }
 
 /* ------------------------------------------------------------- descriptor */
-
-/* atan2(y, x) * 4/pi in (-4, 4]: octant reduction + odd degree-11 minimax polynomial of
- * atan(r) * 4/pi on [0, 1] (max error 2.2e-6 bins = 1.7e-6 rad, fitted offline), v_rcp instead of
- * a division.  Only used for the descriptor's SOFT orientation binning, which is continuous in
- * the angle (the reference uses fast intrinsics there too, s_desc_loop.cu:48,97). */
-__device__ __forceinline__ float atan2_bins(float y, float x)
-{
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float       r = mn * __builtin_amdgcn_rcpf(mx);
-    r = (mx == 0.0f) ? 0.0f : r;
-    const float s = r * r;
-    float       p = fmaf(-0.01492126751691103f, s, 0.06703268736600876f);
-    p = fmaf(p, s, -0.14823880791664124f);
-    p = fmaf(p, s, 0.24642325937747955f);
-    p = fmaf(p, s, -0.42350852489471436f);
-    p = fmaf(p, s, 1.2732105255126953f);
-    float t = p * r;
-    t = (ay > ax) ? 2.0f - t : t;
-    t = (x < 0.0f) ? 4.0f - t : t;
-    return (y < 0.0f) ? -t : t;
-}
 
 /*
  * One wave per (extremum, orientation), no workgroup barrier.  The reference gives every one of the 16 cells

@@ -318,20 +318,28 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         auto bin = [&](int xx, int yy, float gdx, float gdy, bool live) {
             const float dx = xx - x;
             const float dy = yy - y;
-            const int   sq_dist = (int)(dx * dx + dy * dy); /* int truncation, s_orientation.cu:123 */
-            if (live && sq_dist <= sq_thres) {
+            /* int truncation, s_orientation.cu:123 -- as a float (the values are far below 2^24, so truncf, the
+             * comparison with rad^2 and the product with `factor` give what the int round trip gives) */
+            const float sq_dist = truncf(dx * dx + dy * dy);
+            if (live && sq_dist <= (float)sq_thres) {
                 const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
                 const float weight = grad * __expf(sq_dist * factor);
                 /* The bin is a HARD decision, so the angle needs libm-grade accuracy -- but only when it lies next to a
                  * bin edge: the cheap atan2 (the descriptor's one-reciprocal degree-11 polynomial in units of pi / 4:
                  * error < 1.7e-6 rad = 1e-5 of these bins) decides every sample farther than 1e-4 bins from an edge
                  * identically to the accurate one, which the others (1 in 5000) then take. */
-                float       fb = (atan2_bins(gdy, gdx) + 4.0f) * ((float)PS_ORI_NBINS / 8.0f);
+                float fb = (atan2_bins(gdy, gdx) + 4.0f) * ((float)PS_ORI_NBINS / 8.0f);
+                float fl = floorf(fb), fr = fb - fl;
                 /* next to an edge the value is formed exactly as the oracle forms it (product, then IEEE quotient): gradients
                  * of exactly 45 degrees -- frequent in level 0 of the up-scaled octave -- sit ON the edge 22.5, 31.5, ...,
                  * where the two formulas round to different sides */
-                if (fabsf(fb - floorf(fb) - 0.5f) < 1e-4f) fb = (float)PS_ORI_NBINS * (atan2_acc(gdy, gdx) + F_PI) / F_PI2;
-                int         bidx = (int)roundf(fb);
+                if (fabsf(fr - 0.5f) < 1e-4f) {
+                    fb = (float)PS_ORI_NBINS * (atan2_acc(gdy, gdx) + F_PI) / F_PI2;
+                    fl = floorf(fb);
+                    fr = fb - fl;
+                }
+                /* roundf(fb) for fb >= 0: the floor, plus one from the half on (fb - floor is exact) */
+                int bidx = (int)fl + (fr >= 0.5f ? 1 : 0);
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
                 if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));
             }

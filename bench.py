@@ -334,6 +334,23 @@ def main():
                                      "ms_device": round(ms_sp, 4), "pipeline_alg_GBps": round(bs / (ms_sp * 1e-3) / 1e9, 1),
                                      "pipeline_frac_of_8TBps": round(bs / (ms_sp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             sp.close()
+            # ... and its throughput with images in flight (reported extra; pyramid + detection set the pace here)
+            sp_ctxs = [hip.Context(hip.default_params(threshold=0.17), device=local_rank) for _ in range(8)]
+            spw = Workers(sp_ctxs, ptrs)
+            spw.step()
+            torch.cuda.synchronize()
+            t_sp = time.perf_counter()
+            for _ in range(3):
+                spw.step()
+            torch.cuda.synchronize()
+            dt_sp = time.perf_counter() - t_sp
+            spw.close()
+            for c in sp_ctxs:
+                c.close()
+            extra["sparse_image"]["in_flight_8_mpix_s"] = round(3 * len(ptrs) * W * H / 1e6 / dt_sp, 1)
+            extra["sparse_image"]["in_flight_8_ms_per_image"] = round(dt_sp / (3 * len(ptrs)) * 1e3, 4)
+            extra["sparse_image"]["in_flight_8_pipeline_frac_of_8TBps"] = round(
+                bs * 3 * len(ptrs) / dt_sp / 1e9 / HBM_PEAK_GBPS, 4)
             leg("sparse_image")
         # ---- PCIe-inclusive end-to-end rate (host image in, host features out), one context -----------------------
         t1 = time.perf_counter()

@@ -335,7 +335,9 @@ def main():
                                      "pipeline_frac_of_8TBps": round(bs / (ms_sp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             sp.close()
             # ... and its throughput with images in flight (reported extra; pyramid + detection set the pace here)
-            sp_ctxs = [hip.Context(hip.default_params(threshold=0.17), device=local_rank) for _ in range(8)]
+            # four contexts: this regime is HBM-bound, more images in flight only thrash the L2s (2 / 4 / 8 / 16 contexts:
+            # 6.3 / 7.8 / 7.0 / 6.4 Gpix/s, tools/sparse_throughput.py)
+            sp_ctxs = [hip.Context(hip.default_params(threshold=0.17), device=local_rank) for _ in range(4)]
             spw = Workers(sp_ctxs, ptrs)
             spw.step()
             torch.cuda.synchronize()
@@ -347,9 +349,10 @@ def main():
             spw.close()
             for c in sp_ctxs:
                 c.close()
-            extra["sparse_image"]["in_flight_8_mpix_s"] = round(3 * len(ptrs) * W * H / 1e6 / dt_sp, 1)
-            extra["sparse_image"]["in_flight_8_ms_per_image"] = round(dt_sp / (3 * len(ptrs)) * 1e3, 4)
-            extra["sparse_image"]["in_flight_8_pipeline_frac_of_8TBps"] = round(
+            extra["sparse_image"]["in_flight_contexts"] = len(sp_ctxs)
+            extra["sparse_image"]["in_flight_mpix_s"] = round(3 * len(ptrs) * W * H / 1e6 / dt_sp, 1)
+            extra["sparse_image"]["in_flight_ms_per_image"] = round(dt_sp / (3 * len(ptrs)) * 1e3, 4)
+            extra["sparse_image"]["in_flight_pipeline_frac_of_8TBps"] = round(
                 bs * 3 * len(ptrs) / dt_sp / 1e9 / HBM_PEAK_GBPS, 4)
             leg("sparse_image")
         # ---- PCIe-inclusive end-to-end rate (host image in, host features out), one context -----------------------

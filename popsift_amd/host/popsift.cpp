@@ -164,7 +164,7 @@ void bind_to_numa_node(int node)
 int contexts_per_device()
 {
     const char* e = getenv("POPSIFT_CONTEXTS_PER_DEVICE");
-    const int   k = e ? atoi(e) : 4; /* measured: 2 / 4 / 8 contexts = 0.95 / 1.48 / 1.21 Gpix/s host to host (popsift-bench) */
+    const int   k = e ? atoi(e) : 4; /* measured host to host with the in-context download overlap: 1 / 2 / 3 / 4 / 6 / 8 contexts = 1.60 / 1.90 / 2.06 / 2.03 / 2.02 / 1.82 Gpix/s (tools/h2h_sweep.sh) */
     return std::min(std::max(k, 1), 64);
 }
 

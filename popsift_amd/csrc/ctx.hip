@@ -857,7 +857,6 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
             c->kp_waves = std::max(cus, 8) * 32 * 8; /* a multiple of 32 */
         }
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
         HIP_TRY(c, hipEventCreate(&c->ev_end));
         for (int k = 0; k <= POPSIFT_HIP_STAGE_COUNT; k++) HIP_TRY(c, hipEventCreate(&c->ev_stage[k]));
@@ -985,6 +984,10 @@ int popsift_hip_fetch_begin(popsift_hip_ctx* c, popsift_hip_feature* feats, size
     HIP_TRY(c, hipSetDevice(c->device));
     /* the other slab may still be the source of the previous download */
     if (int rc = drain_copy(c)) return rc;
+    /* The copy stream is made on first use: the runtime deals its few hardware queues to streams in the order they
+     * are created, so a second stream in EVERY context -- used or not -- takes queues from the streams that do the work
+     * (four active contexts next to sixteen idle ones: 7.8 -> 6.5 Gpix/s on the sparse workload). */
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     /* nothing has been issued or swapped yet: a failed allocation leaves the results where they are (plain fetch works) */
     if (int rc = grow(c, &c->alt_feats, &c->alt_feats_cap, c->feats_cap)) return rc;
     if (c->alt_desc_cap < c->desc_cap) {

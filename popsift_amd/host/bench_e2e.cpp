@@ -3,7 +3,9 @@
  * (SURVEY 8(d) "T_e2e": wall time per image through enqueue() ... get() with many images in flight).
  * PCIe-inclusive: every image is uploaded and its features + descriptors (about 53 MB for the dense
  * synthetic 1080p image) are downloaded into a FeaturesHost.  Never the headline `value` of bench.py.
- *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--seed S] [--pgm a.pgm,b.pgm,...]
+ *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--seed S] [--pgm a.pgm,b.pgm,...] [--threshold T]
+ * --threshold: popsift::Config::setThreshold (0.04 by default; 0.17 leaves ~2 features per 1000 pixels of the synthetic
+ * images -- the keypoint-sparse regime, where the results are a few MB and PCIe is no longer the limit).
  * --pgm: the images to cycle through (bench.py passes the popsift_amd/synth.py images of the headline workload);
  * without it a cheap built-in generator is used.
  * Contexts per GPU come from POPSIFT_CONTEXTS_PER_DEVICE, GPUs from POPSIFT_DEVICES.
@@ -54,6 +56,7 @@ int main(int argc, char** argv)
 {
     int images = 64, w = 1920, h = 1080, inflight = 16;
     unsigned seed = 1;
+    float    threshold = -1.0f;
     std::string pgm;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--pgm")) pgm = argv[i + 1];
@@ -62,6 +65,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--height")) h = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--inflight")) inflight = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = (unsigned)atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--threshold")) threshold = (float)atof(argv[i + 1]);
     }
     std::vector<std::vector<unsigned char>> pool;
     if (!pgm.empty()) {
@@ -86,6 +90,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 4; k++) pool.push_back(make_image(w, h, seed + k));
 
     popsift::Config config;
+    if (threshold >= 0.0f) config.setThreshold(threshold);
     PopSift         sift(config, popsift::Config::ExtractingMode, PopSift::ByteImages);
 
     auto run = [&](int n, long long& feats, long long& descs) {

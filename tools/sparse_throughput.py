@@ -1,5 +1,6 @@
 """Throughput of the keypoint-sparse regime (threshold 0.17: 2 features / 1000 px) over the number of contexts in flight.
-python3 tools/sparse_throughput.py  (GPU box)"""
+python3 tools/sparse_throughput.py [idle]  (GPU box; `idle`: with 16 idle default contexts alive, as inside bench.py --
+the runtime deals its hardware queues to streams in creation order, so streams that merely exist change the result)"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ W, H = 1920, 1080
 bench.W, bench.H = W, H
 imgs = [torch.from_numpy(synth(100 + k, W, H)).cuda() for k in range(16)]
 ptrs = [imgs[i % 16].data_ptr() for i in range(64)]
+idle = [hip.Context() for _ in range(16)] if len(sys.argv) > 1 else []
 for n in (2, 4, 8, 12, 16, 24):
     ctxs = [hip.Context(hip.default_params(threshold=0.17)) for _ in range(n)]
     w = bench.Workers(ctxs, ptrs)

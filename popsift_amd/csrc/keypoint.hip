@@ -722,11 +722,18 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
  * address, and the two private copies sat exactly 1 KiB apart, on the same banks.  Now
  *   - the wave works as four groups of 16 lanes, each on its own quarter of the sample list (different cell rows),
  *   - four private copies by lane (neighbouring lanes never share a word),
- *   - the word of (copy c, cell iy ix, bin b) is c*128 + iy*32 + ((ix + iy) & 3)*8 + ((b + c + 4*(ix & 1)) & 7):
- *     for lanes that agree in the bin, the copies, the two cell columns a group straddles and the four groups'
- *     cell rows land on 32 different bank pairs.
+ *   - the word of (copy c, cell iy ix, bin b) is c*140 + iy*36 + ix*8 + ((b + c + 4*(ix & 1)) & 7) (DESC_CS, DESC_RS
+ *     below): for lanes that agree in the bin, the copies, the two cell columns a group straddles and the four groups'
+ *     cell rows land on different bank pairs, and the four words of a sample are one address + immediate offsets.
  */
 constexpr int DESC_COPIES = 4;
+/* LINEAR histogram layout: the word (8 bytes) of (copy c, cell row iy, cell column ix, slot s) is
+ * c * DESC_CS + iy * DESC_RS + ix * 8 + s with a cell-row stride of 36 words instead of 32.  The four words of a sample
+ * are then ONE address plus the immediate offsets 0 / 64 / 288 / 352 bytes (no per-cell index arithmetic, cells -1 and
+ * 4 fall out naturally), and the four extra words per row shift consecutive cell rows by four bank pairs, which does
+ * what the (ix + iy) rotation of the 32-word layout did for the four lane groups working on different rows. */
+constexpr int DESC_RS = 36;                /* words per cell row */
+constexpr int DESC_CS = 3 * DESC_RS + 32;  /* words per copy (the last row needs no padding): 140 */
 constexpr int DESC_MAXROWS = 128; /* patch rows handled by the span path */
 #ifndef DESC_GROUPS
 #define DESC_GROUPS 4 /* lane groups, each on its own 1 / DESC_GROUPS of the sample list */
@@ -738,13 +745,13 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                                                        Counters* __restrict__ ct, const DescRec* __restrict__ drec,
                                                        float* __restrict__ desc, int desc_cap)
 {
-    __shared__ __attribute__((aligned(1024))) fix64 s_hist[KP_NW][DESC_COPIES * 128];
+    __shared__ __attribute__((aligned(16))) fix64 s_hist[KP_NW][DESC_COPIES * DESC_CS];
     /* per patch row: flat index of its first sample (20 bits) | first column of its span relative to xmin (12 bits) */
     __shared__ unsigned int s_row[KP_NW][DESC_MAXROWS + 1];
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int     grp = lane / DESC_GL, sub = lane % DESC_GL, cpy = lane & (DESC_COPIES - 1);
     fix64*        hall = s_hist[wave];
-    char*         hbase = (char*)(hall + cpy * 128);
+    char*         hbase = (char*)(hall + cpy * DESC_CS);
     unsigned int* rinfo = s_row[wave];
     const int     total = min(ct->ori_total, desc_cap);
     
@@ -766,7 +773,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
         const float*       layer = arena + uniform64((long long)(((unsigned long long)q2.y << 32) | q2.x));
 
 #pragma unroll
-        for (int k = 0; k < 2 * DESC_COPIES; k++) hall[lane + 64 * k] = 0ull;
+        for (int k = 0; k < (DESC_COPIES * DESC_CS + 63) / 64; k++)
+            if (lane + 64 * k < DESC_COPIES * DESC_CS) hall[lane + 64 * k] = 0ull;
 
         if (misc & (1u << 24)) { /* DESC_MAGNIFY * sigma != 0 */
             const int   xmin = (int)(short)(pmin & 0xffff), ymin = pmin >> 16;
@@ -907,11 +915,12 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     const float wy1 = (cy0 <= 2) ? fy * wm : 0.0f;
                     const float w1 = do0, w0 = 1.0f - do0;
                     /* byte addresses of the four words (a word is only touched when its weight is positive, and then
-                     * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped) */
-                    const int k0 = (cx0 + cy0) & 3;
+                     * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped): one base, the slot of the even and of the odd
+                     * cell column, immediate offsets for the neighbours */
                     const int s0 = ((b0 + cpy + ((cx0 & 1) << 2)) & 7) << 3;
-                    char*     e0 = hbase + (cy0 << 8) + s0;
-                    char*     e1 = hbase + (cy0 << 8) + (s0 ^ 32);
+                    char*     cb = hbase + cy0 * (DESC_RS * 8) + (cx0 << 6);
+                    char*     e0 = cb + s0;
+                    char*     e1 = cb + (s0 ^ 32);
 #define PS_CELL(ADDR, WGT)                                                                \
     {                                                                                     \
         const float wgt = (WGT);                                                          \
@@ -921,10 +930,10 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
             atomicAdd((fix64*)(ADDR), ((fix64)hi << 32) | lo);                           \
         }                                                                                 \
     }
-                    PS_CELL(e0 + (k0 << 6), wy0 * wx0)
-                    PS_CELL(e1 + (((k0 + 1) & 3) << 6), wy0 * wx1)
-                    PS_CELL(e0 + (((k0 + 1) & 3) << 6) + 256, wy1 * wx0)
-                    PS_CELL(e1 + (((k0 + 2) & 3) << 6) + 256, wy1 * wx1)
+                    PS_CELL(e0, wy0 * wx0)
+                    PS_CELL(e1 + 64, wy0 * wx1)
+                    PS_CELL(e0 + DESC_RS * 8, wy1 * wx0)
+                    PS_CELL(e1 + DESC_RS * 8 + 64, wy1 * wx1)
 #undef PS_CELL
                 }
             };
@@ -957,8 +966,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
 #pragma unroll
             for (int k = 0; k < DESC_COPIES; k++) {
                 const int sl = (b + k + ((ix & 1) << 2)) & 7, sh = (b + 7 + k + ((ix & 1) << 2)) & 7;
-                const int c0 = k * 128 + iyl * 32 + ((ix + iyl) & 3) * 8;
-                const int c1 = k * 128 + (iyl + 2) * 32 + ((ix + iyl + 2) & 3) * 8;
+                const int c0 = k * DESC_CS + iyl * DESC_RS + ix * 8;
+                const int c1 = k * DESC_CS + (iyl + 2) * DESC_RS + ix * 8;
                 a0 += (hall[c0 + sl] & 0xffffffffull) + (hall[c0 + sh] >> 32);
                 a1 += (hall[c1 + sl] & 0xffffffffull) + (hall[c1 + sh] >> 32);
             }

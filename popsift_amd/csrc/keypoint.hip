@@ -899,7 +899,6 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     const float tth = atan2_bins(gy, gx) - ang_bins;
                     const float ffo = floorf(tth);
                     const float do0 = tth - ffo;
-                    const int   b0 = (int)ffo & 7;
 
                     /* cell centres sit at integer tu, tv in 0..3; the sample feeds cells
                      * (cx0, cx0+1) x (cy0, cy0+1) with weights (1-fx, fx) x (1-fy, fy)
@@ -917,7 +916,9 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     /* byte addresses of the four words (a word is only touched when its weight is positive, and then
                      * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped): one base, the slot of the even and of the odd
                      * cell column, immediate offsets for the neighbours */
-                    const int s0 = ((b0 + cpy + ((cx0 & 1) << 2)) & 7) << 3;
+                    /* slot of the lower bin: (bin + copy + 4 * (cx0 & 1)) mod 8 -- 4 * cx0 does for 4 * (cx0 & 1) under the
+                     * mask, and the bin needs no mask of its own */
+                    const int s0 = (((int)ffo + cpy + (cx0 << 2)) & 7) << 3;
                     char*     cb = hbase + cy0 * (DESC_RS * 8) + (cx0 << 6);
                     char*     e0 = cb + s0;
                     char*     e1 = cb + (s0 ^ 32);

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context passes (the command the profiles/ *_single_image* files were taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
+    ap.add_argument("--kp-per-cu", type=int, default=0, help="tuning: resident keypoint waves per CU (0 = library default)")
     return ap.parse_args()
 
 
@@ -217,6 +218,9 @@ def main():
     ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
     C = max(1, min(args.contexts, B))
     ctxs = [hip.Context(hip.default_params(), device=local_rank) for _ in range(C)]
+    if args.kp_per_cu:      # tuning runs only (tools/): resident keypoint waves per CU, the library's default otherwise
+        for c in ctxs:
+            c.debug_set(hip.DEBUG_KP_PER_CU, args.kp_per_cu)
     workers = Workers(ctxs, ptrs)
 
     def barrier():
@@ -392,7 +396,8 @@ def main():
                         f.write(im.tobytes())
                 def cpp_leg(per_dev, more=()):
                     r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(4 * per_dev * world),
-                                        "--pgm", ",".join(pgms)] + list(more), capture_output=True, text=True, timeout=180,
+                                        "--callers", str(world), "--pgm", ",".join(pgms)] + list(more),
+                                       capture_output=True, text=True, timeout=180,
                                        env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE=str(per_dev), POPSIFT_DEVICES=devs,
                                                 # every job in flight holds ~82 MB of pinned result blocks: let the pool keep them
                                                 POPSIFT_PINNED_CACHE_MB=str(4 * per_dev * world * 100)))

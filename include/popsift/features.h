@@ -87,6 +87,10 @@ void   releasePinnedCache();
 size_t pinnedCacheBytes();
 /* the NUMA node (or -1) whose free list serves the calling thread's result blocks; PopSift's workers set it */
 void   setPinnedPoolNode(int node);
+/* A block of the same pool (SiftJob keeps its copy of the caller's image in one: no allocation, no page faults and no
+ * second staging copy per job).  *pinned tells whether the block is page-locked (it is not when no GPU runtime is there). */
+void*  pinnedBlockGet(size_t bytes, bool* pinned);
+void   pinnedBlockPut(void* block);
 
 std::ostream& operator<<(std::ostream& ostr, const FeaturesHost& feature);
 

@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h> /* cpu_set_t: a worker's CPUs */
+
 #include "features.h"
 #include "sift_conf.h"
 #include "sift_extremum.h"
@@ -30,8 +32,9 @@ class SiftJob {
     std::future<popsift::FeaturesBase*>  _f;
     int            _w;
     int            _h;
-    unsigned char* _imageData;
+    unsigned char* _imageData; /* this job's copy of the image, in a recycled block of the pinned pool (features.h) */
     bool           _is_float;
+    bool           _pinned = false;
 
 public:
     /** byte image, values 0..255 */
@@ -52,7 +55,14 @@ public:
     int                  getHeight() const { return _h; }
     bool                 isFloat() const { return _is_float; }
     const unsigned char* getImageData() const { return _imageData; }
+    /** extension: the job's image copy is page-locked (the worker then uploads it without a staging copy) */
+    bool                 isPinned() const { return _pinned; }
 };
+
+namespace popsift {
+/* extension: a sysfs cpulist ("0-15,128-143") as a CPU set; returns the number of CPUs named.  Re-entrant. */
+int parseCpuList(const char* list, cpu_set_t* set);
+}  // namespace popsift
 
 class PopSift {
 public:
@@ -103,6 +113,9 @@ private:
         int              device = 0;
         void*            pod = nullptr; /* pinned staging for the POD features of a download */
         size_t           pod_cap = 0;
+        int              numa_node = -1; /* of the GPU; -1 unknown */
+        bool             bind = false;   /* cpus holds the node's CPUs within the process's own affinity mask */
+        cpu_set_t        cpus;
     };
 
     void start_workers(int w, int h);

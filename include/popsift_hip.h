@@ -179,6 +179,12 @@ int popsift_hip_get_gauss_table(const popsift_hip_ctx* ctx, float* filter, int* 
  * u8 values are 0..255, f32 values are [0,1) (popsift.h:108-116). */
 int popsift_hip_submit_u8(popsift_hip_ctx* ctx, const uint8_t* img, int w, int h, int pitch);
 int popsift_hip_submit_f32(popsift_hip_ctx* ctx, const float* img, int w, int h, int pitch);
+/* Same for an image in page-locked host memory (popsift_hip_host_alloc): it is uploaded straight from there, without
+ * the staging copy Image::load makes (s_image.cu:71-79), so the caller keeps it valid and unchanged until
+ * popsift_hip_wait has returned for this image.  PopSift::enqueue's one copy of the caller's image lands in such a
+ * block (popsift.cpp:245-247 makes that copy too, and the upload thread a second one). */
+int popsift_hip_submit_pinned_u8(popsift_hip_ctx* ctx, const uint8_t* img, int w, int h, int pitch);
+int popsift_hip_submit_pinned_f32(popsift_hip_ctx* ctx, const float* img, int w, int h, int pitch);
 /* Same, image already resident in this device's memory (bench "inputs in HBM"). */
 int popsift_hip_submit_dev_u8(popsift_hip_ctx* ctx, const void* d_img, int w, int h, int pitch);
 int popsift_hip_submit_dev_f32(popsift_hip_ctx* ctx, const void* d_img, int w, int h, int pitch);
@@ -272,9 +278,13 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
  * submit: DET_QCAP = candidate-queue entries the fast detection pass may use (small values force strips into the
  * slow pass); CAND_CAP / OHIST_CAP = initial capacity of the candidate buffer / of the orientation-histogram buffer
  * (small values exercise the grow-and-rerun path of popsift_hip_wait); FAIL_ALLOC = n: the n-th device allocation
- * of this context from now on fails with POPSIFT_HIP_ERR_OOM (0 = off). */
+ * of this context from now on fails with POPSIFT_HIP_ERR_OOM (0 = off); DESC_ROWS = patch rows the loop descriptor
+ * walks per pass (4 .. 128, default 128: small values make ordinary patches take the several passes that otherwise only
+ * patches of more than 128 rows take -- sigma0 near 2 at the coarsest level; results do not depend on it); KP_PER_CU =
+ * resident waves per CU of the orientation / loop-descriptor launches (1 .. 32, default 16; a tuning knob: results do not
+ * depend on it). */
 enum { POPSIFT_HIP_DEBUG_DET_QCAP = 1, POPSIFT_HIP_DEBUG_CAND_CAP = 2, POPSIFT_HIP_DEBUG_OHIST_CAP = 3,
-       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4 };
+       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5, POPSIFT_HIP_DEBUG_KP_PER_CU = 6 };
 int popsift_hip_debug_set(popsift_hip_ctx* ctx, int what, int value);
 
 #ifdef __cplusplus

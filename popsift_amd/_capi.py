@@ -92,6 +92,8 @@ SYMBOLS = [
     ("popsift_hip_submit_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("popsift_hip_submit_dev_u8", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("popsift_hip_submit_dev_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_submit_pinned_u8", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_submit_pinned_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("popsift_hip_wait", C.c_int, [_vp, _ip, _ip]),
     ("popsift_hip_fetch", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("popsift_hip_fetch_begin", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
@@ -119,7 +121,7 @@ SYMBOLS = [
 ]
 MATCH_AUTO, MATCH_EXACT, MATCH_SCREEN = 0, 1, 2
 STAGES = ("pyramid", "detect", "refine", "orientation", "scan", "descriptor")
-DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC = 1, 2, 3, 4
+DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC, DEBUG_DESC_ROWS, DEBUG_KP_PER_CU = 1, 2, 3, 4, 5, 6
 
 _lib = None
 
@@ -329,6 +331,12 @@ class Context:
         else:
             raise TypeError("uint8 or float32 image expected, got %s" % img.dtype)
         self._chk(rc, "popsift_hip_submit")
+        return self
+
+    def submit_pinned(self, ptr, w, h, pitch, is_f32=False):
+        """image in page-locked host memory (host_alloc), uploaded without a staging copy; keep it until wait()"""
+        fn = lib().popsift_hip_submit_pinned_f32 if is_f32 else lib().popsift_hip_submit_pinned_u8
+        self._chk(fn(self._h, ptr, w, h, pitch), "popsift_hip_submit_pinned")
         return self
 
     def submit_dev(self, ptr, w, h, pitch, is_f32=False):

@@ -74,8 +74,11 @@ struct popsift_hip_ctx {
     float*  d_arena = nullptr;
     size_t  arena_cap = 0; /* floats */
     PyrDesc pd{};
-    int      kp_waves = 65536; /* launch size of the keypoint kernels in waves (8 per wave slot of the device) */
+    int      kp_waves = 65536; /* launch size of the statically sliced keypoint kernels in waves (8 per wave slot of the device) */
+    int      cus = 256;
+    int      kp_per_cu = 16;   /* resident waves per CU of k_orientation / k_descriptor (keypoint.hip, kp_fetch) */
     int      det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
+    int      desc_rows = 1 << 30;
     int      cand_cap_init = 1 << 20;
     int      ohist_cap_init = 0;
     InitExt* d_iext = nullptr;
@@ -220,6 +223,7 @@ void init_tables(popsift_hip_ctx* c)
     sc.filter_max = p.filter_max_extrema;
     sc.filter_mode = p.filter_sorting;
     sc.det_qcap = c->det_qcap;
+    sc.desc_rows = c->desc_rows;
 }
 
 /* PopSift::private_init, popsift.cpp:89-120 */
@@ -489,6 +493,8 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
         a.shift = shift;
         /* weights of the linear upscale are exactly {0, 1/2}: k_blur_tile's copy / average path */
         a.fast2x = (c->p.upscale_factor == 1.0f && shift == 1.0f && od.w == 2 * c->in_w && od.h == 2 * c->in_h) ? 1 : 0;
+        /* ... and a u8 image whose rows all start on 4-byte boundaries: its texels are fetched as aligned dwords */
+        if (a.fast2x && !is_f32 && (pitch & 3) == 0 && ((uintptr_t)d_img & 3) == 0) a.fast2x = 2;
         a.zero = (int*)c->d_ct; /* this launch clears the image's counters (enqueue_keypoint_stages(c, true)) */
         a.zero_words = (int)(sizeof(Counters) / sizeof(int));
         const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * (double)od.w * od.h;
@@ -522,6 +528,9 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 /* Pyramid::step2 + prep_features: extrema -> orientation -> scan -> descriptors -> features */
 InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iext2 : c->d_iext; }
 
+/* launch size of the resident-wave keypoint kernels: a multiple of 8 (one work-list head per XCD) */
+int kp_resident(const popsift_hip_ctx* c) { return std::max(c->cus, 8) * std::min(std::max(c->kp_per_cu, 1), 32) / 8 * 8; }
+
 /* counters_cleared: the level-0 launch of this image has zeroed d_ct (submit); re-runs clear it here */
 int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
 {
@@ -539,7 +548,7 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
         SYNC_CHK(c, "grid filter");
     }
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_ORIENTATION));
-    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->kp_waves,
+    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, kp_resident(c),
                                   c->stream));
     SYNC_CHK(c, "k_orientation");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_SCAN));
@@ -548,7 +557,8 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
                            std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_drec, c->d_feats, c->desc_cap, c->stream));
     SYNC_CHK(c, "k_scan_local / k_scan_apply");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DESCRIPTOR));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_drec, c->d_desc, c->desc_cap, c->kp_waves,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_drec, c->d_desc, c->desc_cap,
+                                  c->sc.desc_mode == POPSIFT_HIP_DESC_LOOP ? kp_resident(c) : c->kp_waves,
                                   c->stream));
     SYNC_CHK(c, "descriptor kernel");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_COUNT));
@@ -570,27 +580,33 @@ int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32
     const size_t esz = is_f32 ? 4 : 1;
     const void*  d_img = img;
     int          dpitch = pitch;
-    if (!on_device) {
+    if (on_device != 1) {
         size_t cap = c->input_cap;
         char*  buf = (char*)c->d_input;
         const int rc_in = grow(c, &buf, &cap, (size_t)w * h * esz);
         c->d_input = buf; /* also after a failed grow, which has freed the old buffer */
         c->input_cap = cap;
         if (rc_in) return rc_in;
-        /* Like Image::load (s_image.cu:71-79) the caller's buffer is copied into pinned memory before
-         * this call returns: the caller may free or reuse it immediately (popsift.cpp:245-247), and an
-         * async copy straight from pageable memory would read it later. */
         const size_t bytes = (size_t)w * h * esz;
-        if (bytes > c->h_input_cap) {
-            if (c->h_input) HIP_TRY(c, hipHostFree(c->h_input));
-            c->h_input = nullptr;
-            c->h_input_cap = 0;
-            HIP_TRY(c, hipHostMalloc(&c->h_input, bytes, hipHostMallocDefault));
-            c->h_input_cap = bytes;
+        if (on_device == 2) {
+            /* page-locked memory of the caller, valid until wait(): uploaded from where it lies */
+            HIP_TRY(c, hipMemcpy2DAsync(c->d_input, (size_t)w * esz, img, (size_t)pitch * esz, (size_t)w * esz, (size_t)h,
+                                        hipMemcpyHostToDevice, c->stream));
+        } else {
+            /* Like Image::load (s_image.cu:71-79) the caller's buffer is copied into pinned memory before
+             * this call returns: the caller may free or reuse it immediately (popsift.cpp:245-247), and an
+             * async copy straight from pageable memory would read it later. */
+            if (bytes > c->h_input_cap) {
+                if (c->h_input) HIP_TRY(c, hipHostFree(c->h_input));
+                c->h_input = nullptr;
+                c->h_input_cap = 0;
+                HIP_TRY(c, hipHostMalloc(&c->h_input, bytes, hipHostMallocDefault));
+                c->h_input_cap = bytes;
+            }
+            for (int y = 0; y < h; y++)
+                memcpy((char*)c->h_input + (size_t)y * w * esz, (const char*)img + (size_t)y * pitch * esz, (size_t)w * esz);
+            HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_input, bytes, hipMemcpyHostToDevice, c->stream));
         }
-        for (int y = 0; y < h; y++)
-            memcpy((char*)c->h_input + (size_t)y * w * esz, (const char*)img + (size_t)y * pitch * esz, (size_t)w * esz);
-        HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_input, bytes, hipMemcpyHostToDevice, c->stream));
         d_img = c->d_input;
         dpitch = w;
     }
@@ -855,6 +871,7 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
             c->kp_waves = std::max(cus, 8) * 32 * 8; /* a multiple of 32 */
+            c->cus = cus;
         }
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
@@ -939,6 +956,14 @@ int popsift_hip_submit_u8(popsift_hip_ctx* c, const uint8_t* img, int w, int h, 
 int popsift_hip_submit_f32(popsift_hip_ctx* c, const float* img, int w, int h, int pitch)
 {
     return submit_common(c, img, 0, 1, w, h, pitch);
+}
+int popsift_hip_submit_pinned_u8(popsift_hip_ctx* c, const uint8_t* img, int w, int h, int pitch)
+{
+    return submit_common(c, img, 2, 0, w, h, pitch);
+}
+int popsift_hip_submit_pinned_f32(popsift_hip_ctx* c, const float* img, int w, int h, int pitch)
+{
+    return submit_common(c, img, 2, 1, w, h, pitch);
 }
 int popsift_hip_submit_dev_u8(popsift_hip_ctx* c, const void* d_img, int w, int h, int pitch)
 {
@@ -1367,6 +1392,12 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_FAIL_ALLOC:
         c->fail_alloc_in = std::max(value, 0);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_KP_PER_CU:
+        c->kp_per_cu = std::min(std::max(value, 1), 32);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_DESC_ROWS:
+        c->desc_rows = c->sc.desc_rows = std::max(value, 4);
         return POPSIFT_HIP_OK;
     }
     return fail(c, POPSIFT_HIP_ERR_INVALID, "unknown debug switch %d", what);

@@ -77,6 +77,7 @@ __device__ __forceinline__ long long uniform64(long long v)
  * `pitch` are wave-uniform: with an UNSIGNED 32-bit byte offset the loads take the scalar-base + vector-offset
  * form (three scalar bases: the row, the row below, the row above) instead of 64-bit vector address arithmetic
  * per tap.  A plane is far below 4 GiB (the arena's largest is 7680 x 4320 floats). */
+/* ISA: taps */
 struct Taps {
     const char* row;
     const char* dn;
@@ -93,6 +94,7 @@ struct Taps {
     }
 };
 
+/* ISA: end */
 /* element `idx` >= 0 of a wave-uniform plane through an unsigned 32-bit byte offset (scalar base + vector offset) */
 __device__ __forceinline__ float plane_at(const float* pl, int idx)
 {
@@ -132,6 +134,29 @@ __device__ __forceinline__ XcdSlice xcd_slice()
     sl.step = (int)(gridDim.x >> 3) * NW;
     return sl;
 }
+
+/*
+ * The same distribution for RESIDENT waves (round 3).  k_orientation and k_descriptor are launched with far fewer
+ * waves than the device has slots for (ctx.hip: kp_resident), so that wave slots, registers and LDS stay free for the
+ * bandwidth-bound kernels of the other images in flight: as 65536 single-wave workgroups they refilled every slot the
+ * moment it became free, and a blur tile of another stream (8 waves and 43-67 KB of LDS at once on one CU) found no room
+ * until the whole grid had been dispatched -- in the timed loop a 20 us level launch took 117 us on average and three of
+ * the four hardware queues stood still while a k_descriptor ran (profiles/r03_bench_quick_timeline_before.txt).
+ * A static stride over keypoints whose cost spreads 1 : 4 leaves the long ones for the end (round 2: 729 us at 4096
+ * waves), so the resident waves take their positions from a counter per XCD, KP_FETCH at a time -- one returning
+ * atomic per KP_FETCH keypoints (~100 us of work), issued when the wave has nothing else in flight.  Position s of
+ * XCD x is the element XcdSlice::index() gives, so the locality argument above is unchanged.
+ */
+constexpr int KP_FETCH = 4; /* divides KP_CHUNK: a fetch never straddles two chunks */
+static_assert(KP_CHUNK % KP_FETCH == 0, "a fetch stays inside one chunk");
+__device__ __forceinline__ int kp_fetch(int* head, int lane)
+{
+    int s0 = 0;
+    if (lane == 0) s0 = atomicAdd(head, KP_FETCH);
+    return __builtin_amdgcn_readfirstlane(s0);
+}
+__device__ __forceinline__ bool kp_more(int s0, int total) { return (s0 / KP_CHUNK) * 8 * KP_CHUNK < total; }
+__device__ __forceinline__ int kp_index(int s, int x) { return ((s / KP_CHUNK) * 8 + x) * KP_CHUNK + (s % KP_CHUNK); }
 
 /* clamped extrema counts -> exclusive prefix (uniform, <= 20 entries) */
 __device__ __forceinline__ int ext_prefix(const Counters* ct, const SiftConsts& sc, int n_oct, int* ps)
@@ -230,6 +255,7 @@ __device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
  * atan(r) * 4/pi on [0, 1] (max error 2.2e-6 bins = 1.7e-6 rad, fitted offline), v_rcp instead of
  * a division.  Only used for the descriptor's SOFT orientation binning, which is continuous in
  * the angle (the reference uses fast intrinsics there too, s_desc_loop.cu:48,97). */
+/* ISA: magnitude + angle */
 __device__ __forceinline__ float atan2_bins(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
@@ -248,6 +274,30 @@ __device__ __forceinline__ float atan2_bins(float y, float x)
     return (y < 0.0f) ? -t : t;
 }
 
+/* The same with a degree-9 polynomial (max error 1.5e-5 bins = 1.2e-5 rad, fitted offline as a minimax problem) for the
+ * descriptor's soft binning alone: the angle only splits a sample's weight between two neighbouring bins, so 1e-5 bins
+ * moves 1e-5 of a weight.  The largest magnitude is kept off zero inside the v_max3 (a zero gradient has zero weight
+ * whatever its angle), the sign of y is copied with one v_bfi. */
+__device__ __forceinline__ float atan2_bins9(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+    const float r = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = r * r;
+    float       p = fmaf(0.026540832594037056f, s, -0.1084246039390564f);
+    p = fmaf(p, s, 0.22938621044158936f);
+    p = fmaf(p, s, -0.4205572307109833f);
+    p = fmaf(p, s, 1.2730693817138672f);
+    float t = p * r;
+    t = (ay > ax) ? 2.0f - t : t;
+    t = (x < 0.0f) ? 4.0f - t : t;
+    return copysignf(t, y);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) fix64 lds_fix64;
+
+/* ISA: end */
 #ifndef KP_NW
 #define KP_NW 1 /* waves per workgroup of k_orientation / k_descriptor: the waves are independent (one keypoint each) */
 #endif
@@ -277,8 +327,11 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
     __syncthreads();
     const int total = min(ps[n_oct], hist_cap);
 
-    for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
-        const int g = sl.index();
+    static_assert(KP_NW == 1, "resident waves: one wave per workgroup");
+    const int xcd = blockIdx.x & 7;
+    for (int s0 = kp_fetch(&ct->kpq[xcd].n, lane); kp_more(s0, total); s0 = kp_fetch(&ct->kpq[xcd].n, lane))
+    for (int sk = 0; sk < KP_FETCH; sk++) {
+        const int g = kp_index(s0 + sk, xcd);
         if (g >= total) continue;
         int o = 0;
         while (o + 1 < n_oct && g >= ps[o + 1]) o++;
@@ -726,7 +779,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ 
  *     below): for lanes that agree in the bin, the copies, the two cell columns a group straddles and the four groups'
  *     cell rows land on different bank pairs, and the four words of a sample are one address + immediate offsets.
  */
-constexpr int DESC_COPIES = 4;
+#ifndef DESC_NCOPY
+#define DESC_NCOPY 4
+#endif
+constexpr int DESC_COPIES = DESC_NCOPY;
 /* LINEAR histogram layout: the word (8 bytes) of (copy c, cell row iy, cell column ix, slot s) is
  * c * DESC_CS + iy * DESC_RS + ix * 8 + s with a cell-row stride of 36 words instead of 32.  The four words of a sample
  * are then ONE address plus the immediate offsets 0 / 64 / 288 / 352 bytes (no per-cell index arithmetic, cells -1 and
@@ -746,18 +802,23 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                                                        float* __restrict__ desc, int desc_cap)
 {
     __shared__ __attribute__((aligned(16))) fix64 s_hist[KP_NW][DESC_COPIES * DESC_CS];
-    /* per patch row: flat index of its first sample (20 bits) | first column of its span relative to xmin (12 bits) */
+    /* per patch row of the current pass: flat index of its first sample (low 16 bits) | that index minus the first column
+     * of its span relative to xmin (high 16 bits, signed), so that column = flat index - (word >> 16) */
     __shared__ unsigned int s_row[KP_NW][DESC_MAXROWS + 1];
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int     grp = lane / DESC_GL, sub = lane % DESC_GL, cpy = lane & (DESC_COPIES - 1);
     fix64*        hall = s_hist[wave];
-    char*         hbase = (char*)(hall + cpy * DESC_CS);
+    /* 32-bit LDS address of this lane's histogram copy */
+    const unsigned int hbase32 = (unsigned int)(size_t)(lds_fix64*)(hall + cpy * DESC_CS);
     unsigned int* rinfo = s_row[wave];
     const int     total = min(ct->ori_total, desc_cap);
-    
+    /* rows per pass: DESC_MAXROWS, or fewer when a test asks for it (popsift_hip_debug_set DESC_ROWS) */
+    const int     maxrows = min(max(sc.desc_rows, 4), DESC_MAXROWS);
 
-    for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
-        const int d = sl.index();
+    const int xcd = blockIdx.x & 7;
+    for (int s0 = kp_fetch(&ct->kpq[8 + xcd].n, lane); kp_more(s0, total); s0 = kp_fetch(&ct->kpq[8 + xcd].n, lane))
+    for (int sk = 0; sk < KP_FETCH; sk++) {
+        const int d = kp_index(s0 + sk, xcd);
         if (d >= total) continue;
         /* everything about the descriptor is wave-uniform and was worked out by k_scan_apply (DescRec): three 16-byte
          * loads of one address, moved to scalar registers (the taps become scalar-base + 32-bit-offset loads) */
@@ -766,22 +827,39 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
         const u4           q0 = rp[0], q1 = rp[1], q2 = rp[2];
         const float        x = uniformf(__uint_as_float(q0.x)), y = uniformf(__uint_as_float(q0.y));
         const float        crsbp = uniformf(__uint_as_float(q0.z)), srsbp = uniformf(__uint_as_float(q0.w));
-        const float        ang_bins = uniformf(__uint_as_float(q1.x)), fscale = uniformf(__uint_as_float(q1.y));
+        const float        ang_bins = uniformf(__uint_as_float(q1.x));
         const int          pmin = uniform((int)q1.z), pmax = uniform((int)q1.w);
         const unsigned int misc = (unsigned int)uniform((int)q2.z);
         const int          pitch = (int)(misc & 0xffffu), fbits = (int)((misc >> 16) & 0xffu);
         const float*       layer = arena + uniform64((long long)(((unsigned long long)q2.y << 32) | q2.x));
 
+        {
+            /* the zero pair is made here, every time: left to itself the compiler keeps one alive across the whole sample
+             * loop, which is the 65th and 66th vector register (a spill, and with it scratch set-up for every wave) */
+            unsigned int zlo, zhi;
+            asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(zlo), "=v"(zhi));
+            const fix64 zero = ((fix64)zhi << 32) | zlo;
 #pragma unroll
-        for (int k = 0; k < (DESC_COPIES * DESC_CS + 63) / 64; k++)
-            if (lane + 64 * k < DESC_COPIES * DESC_CS) hall[lane + 64 * k] = 0ull;
+            for (int k = 0; k < (DESC_COPIES * DESC_CS + 63) / 64; k++)
+                if (lane + 64 * k < DESC_COPIES * DESC_CS) hall[lane + 64 * k] = zero;
+        }
 
         if (misc & (1u << 24)) { /* DESC_MAGNIFY * sigma != 0 */
-            const int   xmin = (int)(short)(pmin & 0xffff), ymin = pmin >> 16;
+            const int   xmin = (int)(short)(pmin & 0xffff), ymin0 = pmin >> 16;
             const int   xmax = (int)(short)(pmax & 0xffff), ymax = pmax >> 16;
             const int   wx = xmax - xmin + 1;
-            const int   hy = ymax - ymin + 1;
-            const bool  spans = (hy <= DESC_MAXROWS && wx < 4096);
+            const int   hy_all = ymax - ymin0 + 1;
+            const float inv_c = (fabsf(crsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(crsbp) : 0.0f;
+            const float inv_s = (fabsf(srsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(srsbp) : 0.0f;
+            /* the Gaussian window weight comes out of v_exp already multiplied by the fixed-point scale 2^fbits */
+            const float ffbits = (float)fbits;
+
+            /* A patch is walked in passes of at most `maxrows` rows (ONE pass for every patch of sigma0 <= 1.78 at three
+             * levels; the largest the library accepts -- sigma0 = 2, two levels -- spans 173 rows).  The histogram sums are
+             * integers, so the split changes nothing. */
+            for (int rb = 0; rb < hy_all && wx > 0; rb += maxrows) {
+            const int   ymin = ymin0 + rb;
+            const int   hy = min(hy_all - rb, maxrows);
 
             /* Row spans.  The samples that count lie in the square |u|,|v| < 2.5 (cell units, rotated
              * by ang), which fills only 1/(|cos|+|sin|)^2 = 50..100 % of its bounding box.  Per patch
@@ -790,9 +868,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
              * that passes the exact test below.  Intervals are widened by a pixel: they only have
              * to be a superset. */
             int T = 0;
-            if (wx > 0 && hy > 0 && spans) {
-                const float inv_c = (fabsf(crsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(crsbp) : 0.0f;
-                const float inv_s = (fabsf(srsbp) > 1e-20f) ? __builtin_amdgcn_rcpf(srsbp) : 0.0f;
+            {
                 int         carry = 0;
                 for (int r0 = 0; r0 < hy; r0 += 64) {
                     const int r = r0 + lane;
@@ -822,84 +898,85 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                         if (len == 0) jlo = xmin;
                     }
                     const int incl = wave_incl_scan(len);
-                    if (r < hy) rinfo[r] = (unsigned int)(carry + incl - len) | ((unsigned int)(jlo - xmin) << 20);
+                    const int start = carry + incl - len;
+                    if (r < hy) rinfo[r] = (unsigned int)start | ((unsigned int)(start - (jlo - xmin)) << 16);
                     carry += __shfl(incl, 63);
                 }
                 T = carry;
-                if (lane == 0) rinfo[hy] = (unsigned int)T;
+                if (lane == 0) rinfo[hy] = (unsigned int)T | 0x7fff0000u;
             }
             wave_lds_sync();
 
-            const int   loops = spans ? T : ((wx > 0 && hy > 0) ? wx * hy : 0);
-            float       inv_wx = 0.0f; /* bounding-box scan only (a division) */
-            if (!spans) inv_wx = 1.0f / (float)max(wx, 1);
+            const int   loops = T;
             /* every lane group takes its own part of the list */
             const int   quarter = (loops + DESC_GROUPS - 1) / DESC_GROUPS;
             const int   ibeg = grp * quarter, iend = min(ibeg + quarter, loops);
             const int   iters = (quarter + DESC_GL - 1) / DESC_GL;
             int          row = 0;
             unsigned int cur = 0;
-            if (spans && loops > 0) {
+            if (loops > 0) {
                 /* The row that holds the first sample of this lane's GROUP (coord() walks on from there to the lane's
                  * own): the one non-empty row r with start(r) <= key < start(r + 1).  Every row looks at its own
                  * interval, a ballot per group finds it -- two LDS reads instead of the seven dependent ones of a
                  * binary search per lane. */
                 int grow = 0;
-                for (int rb = 0; rb < hy; rb += 64) {
-                    const int  r = rb + lane;
+                for (int rbk = 0; rbk < hy; rbk += 64) {
+                    const int  r = rbk + lane;
                     const bool in = r < hy;
-                    const int  st = in ? (int)(rinfo[r] & 0xfffffu) : 0x7fffffff;
-                    const int  en = in ? (int)(rinfo[r + 1] & 0xfffffu) : 0x7fffffff;
+                    const int  st = in ? (int)(rinfo[r] & 0xffffu) : 0x7fffffff;
+                    const int  en = in ? (int)(rinfo[r + 1] & 0xffffu) : 0x7fffffff;
 #pragma unroll
                     for (int g = 0; g < DESC_GROUPS; g++) {
                         const int                key = min(g * quarter, loops - 1);
                         const unsigned long long m = __ballot(st <= key && key < en);
-                        if (m != 0ull && grp == g) grow = rb + __ffsll((long long)m) - 1;
+                        if (m != 0ull && grp == g) grow = rbk + __ffsll((long long)m) - 1;
                     }
                 }
-                row = grow;
-                cur = rinfo[row];
+                row = rb + grow; /* rows are counted from the top of the PATCH, whatever the pass: see coord() */
+                cur = rinfo[grow];
             }
+
+            /* Sample (row r, column c), both counted from the corner (ymin0, xmin) of the PATCH (so that the arithmetic does not
+             * depend on how the patch is cut into passes): cell-unit position
+             *   u = crsbp * (xmin + c - x) + srsbp * (ymin0 + r - y),  v = crsbp * (ymin0 + r - y) - srsbp * (xmin + c - x)
+             * (n = u - off, dn = n + off = u, s_desc_loop.cu:88-99) as two FMAs each on the small integers c and r; the
+             * keypoint's offset from the patch corner is wave-uniform and goes into u0 / v0.  The taps are addressed from the
+             * patch corner, so the element offset is r * pitch + c. */
+            const float  ox = (float)xmin - x, oy = (float)ymin0 - y;
+            const float  u0 = fmaf(crsbp, ox, srsbp * oy), v0 = fmaf(crsbp, oy, -srsbp * ox);
+            const float* corner = layer + (size_t)(ymin0 * pitch + xmin);
 
             /* Two-stage software pipeline: the coordinates of the lane's next sample are computed and its four
              * gradient taps requested while the current one is being binned, so the L2 round trip of the taps
-             * overlaps the arithmetic.  The loads are unconditional (in-bounds for every span / box position) to
+             * overlaps the arithmetic.  The loads are unconditional (in-bounds for every span position) to
              * keep the vmcnt waits counted. */
-            auto coord = [&](int i, int& off, float& u, float& v) {
-                int ii, jj;
-                if (spans) {
-                    unsigned int nxt = rinfo[row + 1];
-                    while (i >= (int)(nxt & 0xfffffu)) {
-                        row++;
-                        cur = nxt;
-                        nxt = rinfo[row + 1];
-                    }
-                    jj = xmin + (int)(cur >> 20) + (i - (int)(cur & 0xfffffu));
-                    ii = ymin + row;
-                } else { /* enormous patches: plain bounding-box scan */
-                    const int rr = (int)(((float)i + 0.5f) * inv_wx);
-                    ii = rr + ymin;
-                    jj = i - rr * wx + xmin;
+            auto coord = [&](int i, int& off, float& u, float& v) { /* ISA: coordinates */
+                unsigned int nxt = rinfo[row + 1 - rb];
+                while (i >= (int)(nxt & 0xffffu)) {
+                    row++;
+                    cur = nxt;
+                    nxt = rinfo[row + 1 - rb];
                 }
-                const float dx = jj - x, dy = ii - y;
-                /* position in cell units relative to the keypoint: cell (ix,iy) is centred
-                 * at (ix-1.5, iy-1.5); n = u - off, dn = n + off = u (s_desc_loop.cu:88-99) */
-                u = fmaf(crsbp, dx, srsbp * dy);
-                v = fmaf(crsbp, dy, -srsbp * dx);
-                off = __mul24(ii, pitch) + jj;
+                const int   c = i - ((int)cur >> 16);
+                const float fc = (float)c, fr = (float)row;
+                u = fmaf(crsbp, fc, fmaf(srsbp, fr, u0));
+                v = fmaf(crsbp, fr, fmaf(-srsbp, fc, v0));
+                off = __mul24(row, pitch) + c;
             };
             /* one sample: gradient (gx, gy) at cell-unit position (u, v) -> up to four 64-bit LDS atomics */
             auto bin = [&](float u, float v, float gx, float gy, bool live) {
-                if (live && fabsf(u) < 2.5f && fabsf(v) < 2.5f) {
-                    const float  mod = __builtin_amdgcn_sqrtf(gx * gx + gy * gy);
-                    /* exp(-(u^2+v^2)/8) = 2^(-(u^2+v^2) * log2(e)/8) */
-                    const float  ww = __builtin_amdgcn_exp2f(-0.18033688011112042f * (u * u + v * v));
+                if (live && fabsf(u) < 2.5f && fabsf(v) < 2.5f) { /* ISA: control */
+                    /* ISA: magnitude + angle */
+                    const float  mod = __builtin_amdgcn_sqrtf(fmaf(gx, gx, gy * gy));
+                    /* exp(-(u^2+v^2)/8) * 2^fbits = 2^(fbits - (u^2+v^2) * log2(e)/8) */
+                    const float  wm = __builtin_amdgcn_exp2f(fmaf(-0.18033688011112042f, fmaf(u, u, v * v), ffbits)) * mod;
                     /* gradient angle relative to the keypoint orientation in units of one bin; any multiple of 8 may be
                      * missing: floor / fraction / (& 7) below do not care */
-                    const float tth = atan2_bins(gy, gx) - ang_bins;
+                    const float tth = atan2_bins9(gy, gx) - ang_bins;
                     const float ffo = floorf(tth);
                     const float do0 = tth - ffo;
 
+                    /* ISA: weights */
                     /* cell centres sit at integer tu, tv in 0..3; the sample feeds cells
                      * (cx0, cx0+1) x (cy0, cy0+1) with weights (1-fx, fx) x (1-fy, fy)
                      * -- the (1-|n.x|)(1-|n.y|) of s_desc_loop.cu:100-102 -- where inside 0..3 */
@@ -907,43 +984,50 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     const float fcx = floorf(tu), fcy = floorf(tv);
                     const float fx = tu - fcx, fy = tv - fcy;
                     const int   cx0 = (int)fcx, cy0 = (int)fcy;
-                    const float wm = ww * mod * fscale;
-                    const float wx0 = (cx0 >= 0) ? 1.0f - fx : 0.0f;
-                    const float wx1 = (cx0 <= 2) ? fx : 0.0f;
+                    v2f         wxx, w01;
+                    wxx.x = (cx0 >= 0) ? 1.0f - fx : 0.0f;
+                    wxx.y = (cx0 <= 2) ? fx : 0.0f;
                     const float wy0 = (cy0 >= 0) ? (1.0f - fy) * wm : 0.0f;
                     const float wy1 = (cy0 <= 2) ? fy * wm : 0.0f;
-                    const float w1 = do0, w0 = 1.0f - do0;
+                    w01.x = 1.0f - do0;
+                    w01.y = do0;
+                    /* the four cell weights as two packed products */
+                    const v2f p0 = wxx * (v2f){wy0, wy0}, p1 = wxx * (v2f){wy1, wy1};
                     /* byte addresses of the four words (a word is only touched when its weight is positive, and then
                      * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped): one base, the slot of the even and of the odd
                      * cell column, immediate offsets for the neighbours */
                     /* slot of the lower bin: (bin + copy + 4 * (cx0 & 1)) mod 8 -- 4 * cx0 does for 4 * (cx0 & 1) under the
                      * mask, and the bin needs no mask of its own */
-                    const int s0 = (((int)ffo + cpy + (cx0 << 2)) & 7) << 3;
-                    char*     cb = hbase + cy0 * (DESC_RS * 8) + (cx0 << 6);
-                    char*     e0 = cb + s0;
-                    char*     e1 = cb + (s0 ^ 32);
-#define PS_CELL(ADDR, WGT)                                                                \
-    {                                                                                     \
-        const float wgt = (WGT);                                                          \
-        if (wgt > 0.0f) {                                                                 \
-            const unsigned int lo = (unsigned int)fmaf(w0, wgt, 0.5f);                    \
-            const unsigned int hi = (unsigned int)fmaf(w1, wgt, 0.5f);                    \
-            atomicAdd((fix64*)(ADDR), ((fix64)hi << 32) | lo);                           \
-        }                                                                                 \
+                    /* ... as 32-bit LDS byte addresses in integer arithmetic, so that the compiler can use the three-operand
+                     * forms (v_lshl_add, v_add_lshl, v_mad_i32_i24, v_xad) */
+                    const unsigned int s0 = (((unsigned int)(((int)ffo + (cx0 << 2)) + cpy)) << 3) & 56u;
+                    const unsigned int cb = (unsigned int)(__mul24(cy0, DESC_RS * 8) + (int)hbase32) + ((unsigned int)cx0 << 6);
+                    const unsigned int e0 = cb + s0;
+                    const unsigned int e1 = (s0 ^ 32u) + cb;
+/* ISA: atomics */
+#define PS_CELL(ADDR, WGT)                                                                              \
+    {                                                                                                   \
+        const float wgt = (WGT);                                                                        \
+        if (wgt > 0.0f) {                                                                               \
+            const v2f f = __builtin_elementwise_fma(w01, (v2f){wgt, wgt}, (v2f){0.5f, 0.5f});           \
+            __hip_atomic_fetch_add((lds_fix64*)(size_t)(ADDR), ((fix64)(unsigned int)f.y << 32) | (fix64)(unsigned int)f.x, \
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                      \
+        }                                                                                               \
     }
-                    PS_CELL(e0, wy0 * wx0)
-                    PS_CELL(e1 + 64, wy0 * wx1)
-                    PS_CELL(e0 + DESC_RS * 8, wy1 * wx0)
-                    PS_CELL(e1 + DESC_RS * 8 + 64, wy1 * wx1)
+                    PS_CELL(e0, p0.x)
+                    PS_CELL(e1 + 64u, p0.y)
+                    PS_CELL(e0 + DESC_RS * 8u, p1.x)
+                    PS_CELL(e1 + DESC_RS * 8u + 64u, p1.y)
 #undef PS_CELL
                 }
             };
+            /* ISA: control */
             /* two register sets take turns as "being binned" and "in flight" (the loop is unrolled by two so that no
              * value has to be copied from one role to the other) */
             int   off_a = 0, off_b = 0;
             float u_a = 3.0f, v_a = 3.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
             float u_b = 3.0f, v_b = 3.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
-            const Taps taps(layer, pitch);
+            const Taps taps(corner, pitch);
             if (loops > 0) {
                 coord(min(ibeg + sub, loops - 1), off_a, u_a, v_a);
                 taps.load(off_a, a0, a1, a2, a3);
@@ -956,6 +1040,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                 taps.load(off_a, a0, a1, a2, a3);
                 bin(u_b, v_b, b0 - b1, b2 - b3, i + DESC_GL < iend);
             }
+            wave_lds_sync(); /* ISA: end */
+            } /* passes */
         }
         wave_lds_sync();
 

@@ -183,7 +183,74 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
         const int ys0 = clampi(s_iy[0], 0, a.in_h - 1), ys1 = clampi(s_iy[SR - 1] + 1, 0, a.in_h - 1);
         const int RW = xs1 - xs0 + 1, RH = ys1 - ys0 + 1;
         const bool staged = RW * RH <= IN_MAX;
-        if (a.fast2x && staged) {
+        if (MODE == 1 && a.fast2x == 2) {
+            /* Exact 2x upscale of a u8 image whose rows start on 4-byte boundaries (round 3; the general exact-2x path
+             * below explains why the weights are {0, 1/2}).  The source window of the tile -- RHC rows of RWP texels,
+             * replicated beyond the image edges, which is what the clamped fetch of every out-of-range X / Y gives --
+             * is fetched as aligned DWORDS, four texels per lane and load with compile-time row geometry (the byte
+             * loads of the general path took a run-time integer division per texel), converted by v_cvt_f32_ubyte +
+             * the correctly rounded v / 255 (multiply by RN(1/255), one FMA residual, one FMA correction: equal to the
+             * IEEE quotient, i.e. to cudaReadModeNormalizedFloat's table, for all 256 values -- tools/check_div255.py)
+             * without the LUT pass through LDS; the expansion reads three texels per 16-byte chunk of U with no clamp
+             * or parity arithmetic per element.  U is formed in the same operation order: bit-identical planes. */
+            constexpr int RWP = SW / 2 + 4; /* staged texels per row (a multiple of 4)  */
+            constexpr int RHC = SR / 2 + 2; /* staged rows                              */
+            static_assert(RWP % 4 == 0 && RWP * RHC <= IN_MAX, "the source window fits the staging buffer");
+            const int  sx0 = ((tx0 - HP) >> 1) & ~3; /* floor to a multiple of 4 (also for negative values) */
+            const int  sy0 = (ty0 - HALO) >> 1;
+            const bool inside = sx0 >= 0 && sx0 + RWP <= a.in_w && sy0 >= 0 && sy0 + RHC <= a.in_h;
+            const uint8_t* in8 = (const uint8_t*)a.in;
+            auto unit = [](float v) -> float { /* v / 255.0f, correctly rounded, for v = 0 .. 255 */
+                const float r = 0.003921568859368563f; /* RN(1 / 255) */
+                const float q = v * r;
+                return fmaf(fmaf(-255.0f, q, v), r, q);
+            };
+            if (inside) {
+                constexpr int DW = RWP / 4, ND = DW * RHC, NL = (ND + NT - 1) / NT;
+                unsigned int  pk[NL];
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    const int i = tid + k * NT;
+                    if (i < ND) {
+                        const int r = i / DW, c = i - r * DW;
+                        pk[k] = *reinterpret_cast<const unsigned int*>(in8 + (size_t)(sy0 + r) * a.in_pitch + sx0 + 4 * c);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    const int i = tid + k * NT;
+                    if (i < ND) {
+                        v4f f;
+                        f.x = unit((float)(pk[k] & 255u));
+                        f.y = unit((float)((pk[k] >> 8) & 255u));
+                        f.z = unit((float)((pk[k] >> 16) & 255u));
+                        f.w = unit((float)(pk[k] >> 24));
+                        reinterpret_cast<v4f*>(s_in)[i] = f;
+                    }
+                }
+            } else {
+                for (int i = tid; i < RWP * RHC; i += NT) {
+                    const int r = i / RWP, c = i - r * RWP;
+                    const int x = clampi(sx0 + c, 0, a.in_w - 1), y = clampi(sy0 + r, 0, a.in_h - 1);
+                    s_in[i] = unit((float)in8[(size_t)y * a.in_pitch + x]);
+                }
+            }
+            __syncthreads();
+            constexpr int CH = SW / 4; /* 16-byte chunks per LDS row; a chunk starts at an even X (tx0, HP multiples of 4) */
+            for (int idx = tid; idx < SR * CH; idx += NT) {
+                const int    r = idx / CH, c4 = idx - r * CH;
+                const int    Y = ty0 + r - HALO;
+                const float* t = s_in + ((Y >> 1) - sy0) * RWP + (((tx0 + 4 * c4 - HP) >> 1) - sx0);
+                const float  a0 = t[0], a1 = t[1], a2 = t[2];
+                v4f          out = {a0, 0.5f * a0 + 0.5f * a1, a1, 0.5f * a1 + 0.5f * a2};
+                if (Y & 1) {
+                    const float b0 = t[RWP], b1 = t[RWP + 1], b2 = t[RWP + 2];
+                    const v4f   bot = {b0, 0.5f * b0 + 0.5f * b1, b1, 0.5f * b1 + 0.5f * b2};
+                    out = 0.5f * out + 0.5f * bot;
+                }
+                reinterpret_cast<v4f*>(s_t)[idx] = out;
+            }
+        } else if (a.fast2x && staged) {
             /* Exact 2x upscale (upscale_factor = +1, PopSift / VLFeat sampling: source coordinate = X / 2): the
              * 1.8 fixed-point weights of the linear filter are exactly 0 or 1/2 (or 1 with the neighbour index, when the
              * coordinate computes an ulp below an integer -- the same texel), so U is a copy / 2-point / 4-point

@@ -46,6 +46,7 @@ struct SiftConsts {
     int   det_qcap;   /* candidate queue entries the fast detection pass may use (tests shrink it) */
     int   filter_max;  /* Config::getFilterMaxExtrema(), <= 0: grid filter off */
     int   filter_mode; /* POPSIFT_HIP_FILTER_* */
+    int   desc_rows;   /* patch rows k_descriptor walks per pass (tests shrink it) */
 };
 
 /* sift_extremum.h:24-33 InitialExtremum (without the grid-filter bookkeeping) */
@@ -102,6 +103,12 @@ struct Counters {
         int n;
         int pad[31];
     } qcnt[64];
+    /* work-list heads of the resident keypoint waves (keypoint.hip, kp_fetch): [0..7] k_orientation, [8..15]
+     * k_descriptor, one per XCD, each on a cache line of its own */
+    struct {
+        int n;
+        int pad[31];
+    } kpq[16];
 };
 #define DET_SUBQ 64
 

@@ -3,7 +3,12 @@
  * (SURVEY 8(d) "T_e2e": wall time per image through enqueue() ... get() with many images in flight).
  * PCIe-inclusive: every image is uploaded and its features + descriptors (about 53 MB for the dense
  * synthetic 1080p image) are downloaded into a FeaturesHost.  Never the headline `value` of bench.py.
- *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--seed S] [--pgm a.pgm,b.pgm,...] [--threshold T]
+ *   popsift-bench [--images N] [--width W] [--height H] [--inflight K] [--callers C] [--seed S] [--pgm a.pgm,b.pgm,...]
+ *                 [--threshold T]
+ * --callers: threads that enqueue and drain (each its share of the images and of the in-flight budget; default 1, the
+ * reference's demo loop -- bench.py passes one per GPU: a single caller copies about 10 GB/s of images, enough for one GPU
+ * on dense images and not for eight).  The line reports what a caller thread spends per image: in enqueue() (the copy of
+ * the image into a pinned block), blocked in get(), and in the two deletes.
  * --threshold: popsift::Config::setThreshold (0.04 by default; 0.17 leaves ~2 features per 1000 pixels of the synthetic
  * images -- the keypoint-sparse regime, where the results are a few MB and PCIe is no longer the limit).
  * --pgm: the images to cycle through (bench.py passes the popsift_amd/synth.py images of the headline workload);
@@ -21,6 +26,7 @@
 #include <random>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgmread.h"
@@ -54,7 +60,7 @@ static std::vector<unsigned char> make_image(int w, int h, unsigned seed)
 
 int main(int argc, char** argv)
 {
-    int images = 64, w = 1920, h = 1080, inflight = 16;
+    int images = 64, w = 1920, h = 1080, inflight = 16, callers = 1;
     unsigned seed = 1;
     float    threshold = -1.0f;
     std::string pgm;
@@ -64,6 +70,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--width")) w = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--height")) h = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--inflight")) inflight = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--callers")) callers = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = (unsigned)atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--threshold")) threshold = (float)atof(argv[i + 1]);
     }
@@ -93,36 +100,69 @@ int main(int argc, char** argv)
     if (threshold >= 0.0f) config.setThreshold(threshold);
     PopSift         sift(config, popsift::Config::ExtractingMode, PopSift::ByteImages);
 
-    auto run = [&](int n, long long& feats, long long& descs) {
+    if (callers < 1) callers = 1;
+    if (inflight < callers) inflight = callers;
+    struct CallerTime {
+        double    enqueue = 0, get = 0, del = 0;
+        long long feats = 0, descs = 0;
+    };
+    typedef std::chrono::steady_clock clk;
+    auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
+    /* caller t takes images t, t + callers, ... and keeps at most inflight / callers jobs in flight */
+    auto run_caller = [&](int t, int n, CallerTime& ct) {
         std::deque<SiftJob*> q;
-        feats = descs = 0;
-        auto drain_one = [&]() {
-            SiftJob*           j = q.front();
+        const int            mine = inflight / callers + (t < inflight % callers ? 1 : 0);
+        auto                 drain_one = [&]() {
+            SiftJob* j = q.front();
             q.pop_front();
+            clk::time_point    t0 = clk::now();
             popsift::Features* f = j->get();
-            feats += f->getFeatureCount();
-            descs += f->getDescriptorCount();
+            ct.get += since(t0);
+            ct.feats += f->getFeatureCount();
+            ct.descs += f->getDescriptorCount();
+            t0 = clk::now();
             delete f;
             delete j;
+            ct.del += since(t0);
         };
-        for (int i = 0; i < n; i++) {
-            q.push_back(sift.enqueue(w, h, pool[(size_t)i % pool.size()].data()));
-            if ((int)q.size() >= inflight) drain_one();
+        for (int i = t; i < n; i += callers) {
+            const clk::time_point t0 = clk::now();
+            SiftJob*              j = sift.enqueue(w, h, pool[(size_t)i % pool.size()].data());
+            ct.enqueue += since(t0);
+            q.push_back(j);
+            if ((int)q.size() >= mine) drain_one();
         }
         while (!q.empty()) drain_one();
     };
-    long long f = 0, d = 0;
+    auto run = [&](int n, CallerTime& sum) {
+        std::vector<CallerTime>  cts((size_t)callers);
+        std::vector<std::thread> th;
+        for (int t = 1; t < callers; t++) th.emplace_back(run_caller, t, n, std::ref(cts[(size_t)t]));
+        run_caller(0, n, cts[0]);
+        for (auto& x : th) x.join();
+        sum = CallerTime();
+        for (const CallerTime& c : cts) {
+            sum.enqueue += c.enqueue;
+            sum.get += c.get;
+            sum.del += c.del;
+            sum.feats += c.feats;
+            sum.descs += c.descs;
+        }
+    };
+    CallerTime warm, ct;
     /* warm-up: device buffers and one pinned result block per job that can be in flight (allocating pinned
      * memory takes tens of milliseconds per block and stalls every context while it happens) */
-    run(inflight + sift.getContextCount() + 2, f, d);
-    const auto t0 = std::chrono::steady_clock::now();
-    run(images, f, d);
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    run(inflight + sift.getContextCount() + 2, warm);
+    const auto t0 = clk::now();
+    run(images, ct);
+    const double sec = since(t0);
     printf("{\"e2e_host_api_mpix_s\": %.1f, \"images\": %d, \"width\": %d, \"height\": %d, \"contexts\": %d, "
-           "\"in_flight\": %d, \"ms_per_image\": %.3f, \"features_per_image\": %.0f, \"descriptors_per_image\": %.0f, "
-           "\"input\": \"%s\"}\n",
-           (double)images * w * h / sec / 1e6, images, w, h, sift.getContextCount(), inflight, sec * 1e3 / images,
-           (double)f / images, (double)d / images, pgm.empty() ? "built-in generator" : "pgm files");
+           "\"in_flight\": %d, \"callers\": %d, \"ms_per_image\": %.3f, \"features_per_image\": %.0f, "
+           "\"descriptors_per_image\": %.0f, \"caller_us_per_image\": {\"enqueue\": %.1f, \"get_blocked\": %.1f, "
+           "\"delete\": %.1f}, \"input\": \"%s\"}\n",
+           (double)images * w * h / sec / 1e6, images, w, h, sift.getContextCount(), inflight, callers, sec * 1e3 / images,
+           (double)ct.feats / images, (double)ct.descs / images, ct.enqueue * 1e6 / images, ct.get * 1e6 / images,
+           ct.del * 1e6 / images, pgm.empty() ? "built-in generator" : "pgm files");
     sift.uninit();
     return 0;
 }

@@ -61,7 +61,7 @@ class BlockPool {
     }
 
 public:
-    void* get(size_t bytes, int node)
+    void* get(size_t bytes, int node, bool* pinned = 0)
     {
         const size_t cap = round_up(bytes);
         {
@@ -72,6 +72,7 @@ public:
                 _free.erase(it);
                 _cached -= b.cap;
                 _live[b.p] = b;
+                if (pinned) *pinned = b.pinned;
                 return b.p;
             }
         }
@@ -82,6 +83,7 @@ public:
         }
         std::lock_guard<std::mutex> lk(_m);
         _live[b.p] = b;
+        if (pinned) *pinned = b.pinned;
         return b.p;
     }
     void put(void* p)
@@ -133,6 +135,8 @@ thread_local int t_pool_node = -1;
 void   setPinnedPoolNode(int node) { t_pool_node = node; }
 void   releasePinnedCache() { pool().trim(); }
 size_t pinnedCacheBytes() { return pool().cached_bytes(); }
+void*  pinnedBlockGet(size_t bytes, bool* pinned) { return pool().get(std::max<size_t>(bytes, 1), t_pool_node, pinned); }
+void   pinnedBlockPut(void* block) { pool().put(block); }
 
 FeaturesHost::FeaturesHost() : _ext(0), _ori(0) {}
 

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <map>
 #include <sstream>
 #include <vector>
 
@@ -131,34 +132,65 @@ void print_gauss_tables(const popsift::Config& conf, popsift_hip_ctx* ctx)
 
 std::atomic<int> g_live_pipelines{0}; /* PopSift objects with running workers */
 
-/* Bind the calling worker thread to the CPUs of the NUMA node its GPU hangs off (one host thread per
- * context, NUMA-local pinned buffers): the image staging copy and every pinned block the worker allocates afterwards
- * are then first touched on that node.  Quietly does nothing where the host does not expose the topology. */
-void bind_to_numa_node(int node)
+}  // namespace
+
+namespace popsift {
+/* "0-15,128-143" (a sysfs cpulist) -> CPU set; returns the number of CPUs named.  Re-entrant: several workers parse at
+ * once (strtok, which an earlier version used, keeps one process-wide state).  Exported for the unit test. */
+int parseCpuList(const char* list, cpu_set_t* set)
 {
-    if (node < 0) return;
+    CPU_ZERO(set);
+    int         n = 0;
+    const char* p = list;
+    while (p && *p) {
+        while (*p == ',' || *p == ' ' || *p == '\n' || *p == '\t') p++;
+        if (!*p) break;
+        char*      end = 0;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break; /* not a number: stop at what has been understood so far */
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1) break;
+            p = end;
+        }
+        for (long c = std::max(a, 0L); c <= b && c < CPU_SETSIZE; c++)
+            if (!CPU_ISSET((int)c, set)) {
+                CPU_SET((int)c, set);
+                n++;
+            }
+        while (*p && *p != ',') p++; /* e.g. a stride suffix ":2" is ignored */
+    }
+    return n;
+}
+}  // namespace popsift
+
+namespace {
+
+/* The CPUs of the NUMA node a GPU hangs off (one host thread per context, NUMA-local pinned buffers),
+ * INTERSECTED with the affinity mask the process was started with: a launcher's taskset / numactl / MPI binding is
+ * respected, and when it leaves no CPU of that node the worker is not bound at all.  POPSIFT_NUMA_BIND=0 switches the
+ * binding off (the reference never touches affinity).  Returns false when there is nothing to apply. */
+bool numa_cpu_set(int node, cpu_set_t* out)
+{
+    const char* e = getenv("POPSIFT_NUMA_BIND");
+    if (e && atoi(e) == 0) return false;
+    if (node < 0) return false;
     char path[96];
     snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
     FILE* f = fopen(path, "r");
-    if (!f) return;
-    char list[4096] = {0};
+    if (!f) return false;
+    char       list[4096] = {0};
     const bool ok = fgets(list, sizeof(list), f) != 0;
     fclose(f);
-    if (!ok) return;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    int n = 0;
-    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(0, ",\n")) { /* "0-15,128-143" */
-        int a = 0, b = 0;
-        const int k = sscanf(tok, "%d-%d", &a, &b);
-        if (k == 1) b = a;
-        if (k < 1) continue;
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++) {
-            CPU_SET(c, &set);
-            n++;
-        }
-    }
-    if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    if (!ok) return false;
+    cpu_set_t node_set, cur;
+    if (popsift::parseCpuList(list, &node_set) <= 0) return false;
+    CPU_ZERO(&cur);
+    if (pthread_getaffinity_np(pthread_self(), sizeof(cur), &cur) != 0) return false;
+    CPU_AND(out, &node_set, &cur);
+    return CPU_COUNT(out) > 0;
 }
 
 int contexts_per_device()
@@ -172,10 +204,13 @@ int contexts_per_device()
 
 /* ------------------------------------------------------------------------- SiftJob */
 
+/* The job's copy of the caller's image (the caller may free or reuse its buffer as soon as enqueue() returns,
+ * popsift.cpp:245-247) goes into a recycled block of the pinned pool: no malloc -- a 2 MB malloc is an mmap and 512 page
+ * faults every time -- and no second copy, the worker uploads straight from the block (popsift_hip_submit_pinned_*). */
 SiftJob::SiftJob(int w, int h, const unsigned char* imageData) : _w(w), _h(h), _is_float(false)
 {
     _f = _p.get_future();
-    _imageData = (unsigned char*)malloc((size_t)w * h);
+    _imageData = (unsigned char*)popsift::pinnedBlockGet((size_t)w * h, &_pinned);
     if (_imageData == 0) DIE("Memory limitation: failed to allocate memory for SiftJob");
     memcpy(_imageData, imageData, (size_t)w * h);
 }
@@ -183,12 +218,12 @@ SiftJob::SiftJob(int w, int h, const unsigned char* imageData) : _w(w), _h(h), _
 SiftJob::SiftJob(int w, int h, const float* imageData) : _w(w), _h(h), _is_float(true)
 {
     _f = _p.get_future();
-    _imageData = (unsigned char*)malloc((size_t)w * h * sizeof(float));
+    _imageData = (unsigned char*)popsift::pinnedBlockGet((size_t)w * h * sizeof(float), &_pinned);
     if (_imageData == 0) DIE("Memory limitation: failed to allocate memory for SiftJob");
     memcpy(_imageData, imageData, (size_t)w * h * sizeof(float));
 }
 
-SiftJob::~SiftJob() { free(_imageData); }
+SiftJob::~SiftJob() { popsift::pinnedBlockPut(_imageData); }
 
 void SiftJob::setFeatures(popsift::FeaturesBase* f) { _p.set_value(f); }
 
@@ -243,10 +278,26 @@ void PopSift::start_workers(int w, int h)
     const popsift_hip_params p = to_params(_config);
     const std::vector<int>   devs = device_list();
     const int                per = contexts_per_device();
+    /* the CPU set of every device's NUMA node, worked out once, here, under the lock */
+    std::map<int, std::pair<bool, cpu_set_t>> node_cpus;
+    std::map<int, int>                        node_of;
+    for (int d : devs) {
+        if (node_of.count(d)) continue;
+        int node = -1;
+        if (popsift_hip_device_numa_node(d, &node) != POPSIFT_HIP_OK) node = -1;
+        node_of[d] = node;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        const bool have = numa_cpu_set(node, &set);
+        node_cpus[d] = std::make_pair(have, set);
+    }
     for (int k = 0; k < per; k++) {
         for (int d : devs) {
             Worker* wk = new Worker;
             wk->device = d;
+            wk->numa_node = node_of[d];
+            wk->bind = node_cpus[d].first;
+            wk->cpus = node_cpus[d].second;
             const int rc = popsift_hip_ctx_create(d, &p, &wk->ctx);
             if (rc != POPSIFT_HIP_OK) DIE(string("cannot create extraction context: ") + popsift_hip_strerror(rc));
             _workers.push_back(wk);
@@ -284,11 +335,9 @@ static void convert_features(const popsift_hip_feature* pod, int nf, popsift::Fe
  * With nothing queued the pending download is completed at once, so a lone job sees no added latency. */
 void PopSift::worker_loop(Worker* me)
 {
-    {
-        int node = -1;
-        if (popsift_hip_device_numa_node(me->device, &node) == POPSIFT_HIP_OK) bind_to_numa_node(node);
-        popsift::setPinnedPoolNode(node); /* result blocks this thread takes come from / go to its node's free list */
-    }
+    /* the image upload and every pinned block this worker allocates are then first touched on its GPU's node */
+    if (me->bind) (void)pthread_setaffinity_np(pthread_self(), sizeof(me->cpus), &me->cpus);
+    popsift::setPinnedPoolNode(me->numa_node); /* result blocks this thread takes come from / go to its node's free list */
     /* --log dumps read the context's planes after the image: keep those runs strictly serial */
     const bool overlap = _config.getLogMode() != popsift::Config::All;
     struct {
@@ -324,11 +373,13 @@ void PopSift::worker_loop(Worker* me)
         }
         POPSIFT_RANGE("PopSift job (submit, wait, fetch)");
         int rc;
+        /* the job's block stays untouched until the job is deleted, i.e. beyond popsift_hip_wait below */
         if (job->isFloat())
-            rc = popsift_hip_submit_f32(me->ctx, (const float*)job->getImageData(), job->getWidth(), job->getHeight(),
-                                        job->getWidth());
+            rc = (job->isPinned() ? popsift_hip_submit_pinned_f32 : popsift_hip_submit_f32)(
+                me->ctx, (const float*)job->getImageData(), job->getWidth(), job->getHeight(), job->getWidth());
         else
-            rc = popsift_hip_submit_u8(me->ctx, job->getImageData(), job->getWidth(), job->getHeight(), job->getWidth());
+            rc = (job->isPinned() ? popsift_hip_submit_pinned_u8 : popsift_hip_submit_u8)(
+                me->ctx, job->getImageData(), job->getWidth(), job->getHeight(), job->getWidth());
         if (rc != POPSIFT_HIP_OK) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
         complete_pending(); /* the previous image's download and conversion, under this image's kernels */
         int nf = 0, nd = 0;

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <vector>
 
 #define CHECK(c)                                                         \
     do {                                                                 \
@@ -86,6 +88,51 @@ int main()
     }
     popsift::releasePinnedCache();
     CHECK(popsift::pinnedCacheBytes() == 0);
+
+    // a SiftJob keeps its copy of the image in a block of the same pool: the caller's buffer is free at once, and the
+    // block of a deleted job serves the next one (no allocation per job)
+    {
+        std::vector<unsigned char> img(640 * 480, 7);
+        SiftJob*                   j = new SiftJob(640, 480, img.data());
+        const unsigned char*       where = j->getImageData();
+        img.assign(img.size(), 9);
+        CHECK(where != img.data() && where[0] == 7 && where[640 * 480 - 1] == 7 && ((size_t)where % 4096) == 0);
+        delete j;
+        SiftJob k(640, 480, img.data());
+        CHECK(k.getImageData() == where && k.getImageData()[5] == 9);
+        std::vector<float> fimg(64 * 48, 0.5f);
+        SiftJob            jf(64, 48, fimg.data());
+        CHECK(jf.isFloat() && ((const float*)jf.getImageData())[64 * 48 - 1] == 0.5f);
+    }
+    popsift::releasePinnedCache();
+
+    // the sysfs cpulist parser behind the workers' NUMA binding, from several threads at once (an earlier version used
+    // strtok, whose single process-wide state made concurrent workers corrupt each other's parse)
+    {
+        std::vector<std::thread> th;
+        std::vector<int>         bad(8, 0);
+        for (int t = 0; t < 8; t++)
+            th.emplace_back([t, &bad] {
+                for (int it = 0; it < 2000; it++) {
+                    cpu_set_t set;
+                    char      list[64];
+                    std::snprintf(list, sizeof(list), "%d-%d,%d-%d,%d\n", t, t + 3, 64 + t, 64 + t + 7, 200 + t);
+                    const int n = popsift::parseCpuList(list, &set);
+                    bool      ok = (n == 13) && CPU_COUNT(&set) == 13;
+                    for (int c = t; c <= t + 3; c++) ok = ok && CPU_ISSET(c, &set);
+                    for (int c = 64 + t; c <= 64 + t + 7; c++) ok = ok && CPU_ISSET(c, &set);
+                    ok = ok && CPU_ISSET(200 + t, &set) && !CPU_ISSET(t + 4, &set);
+                    if (!ok) bad[t]++;
+                }
+            });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < 8; t++) CHECK(bad[t] == 0);
+        cpu_set_t set;
+        CHECK(popsift::parseCpuList("", &set) == 0 && popsift::parseCpuList("\n", &set) == 0);
+        CHECK(popsift::parseCpuList("0-3,2-5", &set) == 6 && CPU_COUNT(&set) == 6);   // overlapping ranges count once
+        CHECK(popsift::parseCpuList("7", &set) == 1 && CPU_ISSET(7, &set));
+        CHECK(popsift::parseCpuList("0-1,junk", &set) == 2);                            // stops at what it understands
+    }
 
     // a PopSift object can be made and torn down without ever touching a GPU
     {

@@ -5,17 +5,21 @@
 // hashes over (x, y, sigma, num_ori, k, orientation[k], the 128 descriptor words) of every orientation, which the
 // Python side recomputes from a single-context C-ABI run of the same image -- and dumps the full result of the
 // images named by --dump for the comparison with the oracle.
-//   host_batch_test <out_dir> [--opencv] [--dump i,j,k] a.pgm b.pgm ...
+//   host_batch_test <out_dir> [--opencv] [--dump i,j,k] [--callers K] [--repeat R] [--window W] a.pgm b.pgm ...
+// --callers K: K threads enqueue and collect (thread t takes jobs t, t + K, ...), each with at most W (default: all)
+// of its jobs in flight; --repeat R: the file list R times over (job i is file i mod #files).
 #include <popsift/features.h>
 #include <popsift/popsift.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../popsift_amd/host/pgmread.h"
@@ -38,6 +42,7 @@ int main(int argc, char** argv)
     const std::string        out = argv[1];
     bool                     opencv = false;
     std::set<int>            dump;
+    int                      callers = 1, repeat = 1, window = 0;
     std::vector<std::string> files;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
@@ -47,7 +52,13 @@ int main(int argc, char** argv)
             std::stringstream ss(argv[++i]);
             std::string       t;
             while (std::getline(ss, t, ',')) dump.insert(atoi(t.c_str()));
-        } else
+        } else if (a == "--callers" && i + 1 < argc)
+            callers = std::max(atoi(argv[++i]), 1);
+        else if (a == "--repeat" && i + 1 < argc)
+            repeat = std::max(atoi(argv[++i]), 1);
+        else if (a == "--window" && i + 1 < argc)
+            window = atoi(argv[++i]);
+        else
             files.push_back(a);
     }
     popsift::Config config;
@@ -66,11 +77,11 @@ int main(int argc, char** argv)
         if (!im.p) return 3;
         imgs.push_back(im);
     }
-    PopSift               sift(config);
-    std::vector<SiftJob*> jobs;
-    for (const Img& im : imgs) jobs.push_back(sift.enqueue(im.w, im.h, im.p)); /* all in flight at once */
-    for (size_t i = 0; i < jobs.size(); i++) {
-        popsift::Features*   f = jobs[i]->get();
+    PopSift                  sift(config);
+    const size_t             njobs = imgs.size() * (size_t)repeat;
+    std::vector<std::string> lines(njobs);
+    auto collect = [&](size_t i, SiftJob* job) {
+        popsift::Features*   f = job->get();
         popsift::Descriptor* base = f->getDescriptors();
         uint64_t             digest = 0;
         for (auto it = f->begin(); it != f->end(); ++it) {
@@ -87,11 +98,13 @@ int main(int argc, char** argv)
                 digest += h;
             }
         }
-        printf("%zu %d %d %016llx\n", i, f->getFeatureCount(), f->getDescriptorCount(), (unsigned long long)digest);
+        char buf[96];
+        snprintf(buf, sizeof(buf), "%zu %d %d %016llx", i, f->getFeatureCount(), f->getDescriptorCount(), (unsigned long long)digest);
+        lines[i] = buf;
         if (dump.count((int)i)) {
             const std::string path = out + "/result_" + std::to_string(i) + ".bin";
             FILE*             fp = fopen(path.c_str(), "wb");
-            if (!fp) return 4;
+            if (!fp) exit(4);
             const int32_t nf = f->getFeatureCount(), nd = f->getDescriptorCount();
             fwrite(&nf, 4, 1, fp);
             fwrite(&nd, 4, 1, fp);
@@ -111,8 +124,26 @@ int main(int argc, char** argv)
             fclose(fp);
         }
         delete f;
-        delete jobs[i];
-    }
+        delete job;
+    };
+    auto caller = [&](int t) {
+        std::vector<std::pair<size_t, SiftJob*>> q; /* in flight, oldest first */
+        size_t                                   head = 0;
+        for (size_t i = (size_t)t; i < njobs; i += (size_t)callers) {
+            const Img& im = imgs[i % imgs.size()];
+            q.emplace_back(i, sift.enqueue(im.w, im.h, im.p));
+            if (window > 0 && q.size() - head >= (size_t)window) {
+                collect(q[head].first, q[head].second);
+                head++;
+            }
+        }
+        for (; head < q.size(); head++) collect(q[head].first, q[head].second);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < callers; t++) th.emplace_back(caller, t);
+    caller(0);
+    for (auto& x : th) x.join();
+    for (const std::string& l : lines) printf("%s\n", l.c_str());
     sift.uninit();
     for (Img& im : imgs) delete[] im.p;
     fflush(stdout);

@@ -30,9 +30,12 @@ static std::vector<unsigned char> image(int w, int h, unsigned seed)
     return v;
 }
 
-int main()
+// host_mt_test [callers [jobs per caller]]   (default 4 x 12; the worker pool comes from POPSIFT_DEVICES /
+// POPSIFT_CONTEXTS_PER_DEVICE, e.g. POPSIFT_DEVICES=0,0 for two workers' worth of contexts on one card)
+int main(int argc, char** argv)
 {
     const int                               W = 320, H = 240, NIMG = 6;
+    const int                               CALLERS = argc > 1 ? std::atoi(argv[1]) : 4, PER = argc > 2 ? std::atoi(argv[2]) : 12;
     std::vector<std::vector<unsigned char>> imgs;
     for (int i = 0; i < NIMG; i++) imgs.push_back(image(W, H, 17u + (unsigned)i));
 
@@ -52,14 +55,14 @@ int main()
         }
         sift.uninit();
     }
-    // 4 caller threads x 12 jobs into one object, a second object running at the same time
+    // CALLERS caller threads x PER jobs into one object, a second object running at the same time
     PopSift                  a(config), b(config, popsift::Config::MatchingMode);
     std::vector<std::thread> th;
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < CALLERS; t++)
         th.emplace_back([&, t] {
             std::vector<SiftJob*> jobs;
             std::vector<int>      which;
-            for (int k = 0; k < 12; k++) {
+            for (int k = 0; k < PER; k++) {
                 const int i = (t * 5 + k) % NIMG;
                 jobs.push_back(a.enqueue(W, H, imgs[(size_t)i].data()));
                 which.push_back(i);

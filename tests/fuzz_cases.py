@@ -6,7 +6,7 @@ import time
 import numpy as np
 
 from popsift_amd.synth import synth
-from util import bits, compare_features
+from util import bits, compare_features, descriptor_parity
 
 
 def random_case(rng, case, max_w=700, max_h=500):
@@ -55,11 +55,12 @@ def check_case(O, hip, kw, img, threads=16):
             if ext_ok:
                 st = compare_features(*orc.fetch(), *ctx.fetch())
                 n = max(st["n_desc"], 1)
-                # grid snaps its sample points to pixels: a few percent of descriptors differ by up to 1e-1
-                lim = max(3, n // 20) if kw["desc_mode"] == 2 else max(2, n // 1000)
-                dok = st["missing"] == 0 and st["desc_bad"] <= lim and st["max_sigma_rel"] < 1e-5 and st["max_desc"] < 1e-1
+                # the bars of the named cases (util.descriptor_parity)
+                grid = kw["desc_mode"] == 2
+                pok, pmsg = descriptor_parity(st, grid_mode=grid, thin_grid=grid and min(img.shape) <= 48)
+                dok = st["missing"] == 0 and st["max_sigma_rel"] < 1e-5 and pok
                 ok = ok and dok
-                msg = "desc_bad %d/%d max %.1e" % (st["desc_bad"], n, st["max_desc"])
+                msg = pmsg if not dok else "desc_bad %d/%d max %.1e" % (st["desc_bad"], n, st["max_desc"])
             else:
                 msg = "EXTREMA DIFFER %d vs %d" % (len(eo), len(eh))
         else:

@@ -197,6 +197,12 @@ def test_concurrent_callers_and_two_objects(gpu_hip):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "host_mt_test ok" in r.stdout
+    # eight callers into a pool of 2 x 2 contexts on one card (POPSIFT_DEVICES=0,0): more callers than workers, two
+    # "devices" sharing the queue and the pinned pools
+    r = subprocess.run([exe, "8", "9"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, POPSIFT_DEVICES="0,0", POPSIFT_CONTEXTS_PER_DEVICE="2"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "host_mt_test ok" in r.stdout
 
 
 def test_demo_command_line_errors():

@@ -30,7 +30,7 @@ def compare_features(fa, da, fb, db, tol_desc=1e-3, tol_ang=1e-3):
     """fa/da = oracle, fb/db = device.  Returns a dict of parity statistics."""
     pairs, missing = match_features(fa, fb)
     st = dict(n_a=len(fa), n_b=len(fb), matched=len(pairs), missing=missing, num_ori_diff=0,
-              desc_bad=0, ang_bad=0, n_desc=0, max_desc=0.0, max_ang=0.0, max_sigma_rel=0.0)
+              desc_bad=0, ang_bad=0, n_desc=0, max_desc=0.0, max_ang=0.0, max_sigma_rel=0.0, unexplained=0, offenders=[])
     for ia, ib in pairs:
         a, b = fa[ia], fb[ib]
         st["max_sigma_rel"] = max(st["max_sigma_rel"], abs(float(a["sigma"]) - float(b["sigma"])) / float(a["sigma"]))
@@ -49,7 +49,49 @@ def compare_features(fa, da, fb, db, tol_desc=1e-3, tol_ang=1e-3):
             st["max_desc"] = max(st["max_desc"], rel)
             if rel > tol_desc:
                 st["desc_bad"] += 1
+                # A descriptor is computed in the frame of its keypoint orientation: when the two sides' orientations differ
+                # by dth (the orientation comes out of a HARD-binned histogram, s_orientation.cu:129, where an ulp of atan2
+                # moves a sample to the neighbouring bin), the descriptors differ by a few times dth although each is right
+                # for its frame.  Such an offender is "explained"; one whose orientations agree is not.
+                explained = rel <= EXPLAIN_FACTOR * dth + tol_desc
+                if not explained:
+                    st["unexplained"] += 1
+                st["offenders"].append(dict(octave=int(a["debug_octave"]), x=float(a["xpos"]), y=float(a["ypos"]), k=k,
+                                            sigma=float(a["sigma"]), d_angle=dth, d_desc=rel, explained=explained))
     return st
+
+
+EXPLAIN_FACTOR = 8.0  # relative L2 change of a descriptor per radian of frame rotation, generously (measured 2 .. 5)
+
+
+def descriptor_parity(st, grid_mode=False, thin_grid=False):
+    """The descriptor bars of the GPU parity tests, one place for named cases, configs 4 / 5 and the fuzz slice.
+    Returns (ok, message); the message names every offending keypoint.
+
+    loop / iloop / notile / igrid (continuous in all inputs):
+      - descriptors outside 1e-3 relative L2 whose keypoint orientation AGREES with the oracle's: <= max(1, n // 5000);
+      - descriptors outside 1e-3 that are explained by an orientation difference (above): they are the orientation
+        differences already bounded by ang_bad <= max(2, n // 2000), so the same bound;
+      - nothing beyond 3e-2, angles within 3e-2.
+    grid (s_desc_grid.cu:77 snaps 4096 sample points per descriptor to pixels, so an ulp of orientation flips a point
+    now and then): >= 98 % within 1e-3, all within 6e-2.  thin_grid: images so thin that every keypoint sits
+    at a clamped border, where a flipped point is a step: >= 75 % within 1e-3, all within 2e-1."""
+    n = max(st["n_desc"], 1)
+    expl = st["desc_bad"] - st["unexplained"]
+    if thin_grid:
+        ok = st["desc_bad"] <= max(3, n // 4) and st["max_desc"] < 2e-1
+    elif grid_mode:
+        ok = st["desc_bad"] <= max(3, n // 50) and st["max_desc"] < 6e-2 and st["max_ang"] < 3e-2
+    else:
+        ok = (st["unexplained"] <= max(1, n // 5000) and expl <= max(2, n // 2000)
+              and st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2)
+    msg = "%d of %d descriptors outside 1e-3 (%d with agreeing orientation, %d explained by an orientation difference), max %.2e; " \
+          "angles: %d outside 1e-3 rad, max %.2e" % (st["desc_bad"], n, st["unexplained"], expl, st["max_desc"], st["ang_bad"], st["max_ang"])
+    for o in st["offenders"][:20]:
+        msg += "\n    octave %d (%.3f, %.3f) sigma %.3f ori %d: d_angle %.2e d_desc %.2e %s" % (
+            o["octave"], o["x"], o["y"], o["sigma"], o["k"], o["d_angle"], o["d_desc"],
+            "explained" if o["explained"] else "UNEXPLAINED")
+    return ok, msg
 
 
 def sorted_features(feats, desc):

@@ -51,7 +51,6 @@ def parse():
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context passes (the command the profiles/ *_single_image* files were taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
-    ap.add_argument("--kp-per-cu", type=int, default=0, help="tuning: resident keypoint waves per CU (0 = library default)")
     return ap.parse_args()
 
 
@@ -218,9 +217,6 @@ def main():
     ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
     C = max(1, min(args.contexts, B))
     ctxs = [hip.Context(hip.default_params(), device=local_rank) for _ in range(C)]
-    if args.kp_per_cu:      # tuning runs only (tools/): resident keypoint waves per CU, the library's default otherwise
-        for c in ctxs:
-            c.debug_set(hip.DEBUG_KP_PER_CU, args.kp_per_cu)
     workers = Workers(ctxs, ptrs)
 
     def barrier():

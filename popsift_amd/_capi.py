@@ -121,7 +121,7 @@ SYMBOLS = [
 ]
 MATCH_AUTO, MATCH_EXACT, MATCH_SCREEN = 0, 1, 2
 STAGES = ("pyramid", "detect", "refine", "orientation", "scan", "descriptor")
-DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC, DEBUG_DESC_ROWS, DEBUG_KP_PER_CU = 1, 2, 3, 4, 5, 6
+DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC, DEBUG_DESC_ROWS = 1, 2, 3, 4, 5
 
 _lib = None
 

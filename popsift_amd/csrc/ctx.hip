@@ -74,9 +74,7 @@ struct popsift_hip_ctx {
     float*  d_arena = nullptr;
     size_t  arena_cap = 0; /* floats */
     PyrDesc pd{};
-    int      kp_waves = 65536; /* launch size of the statically sliced keypoint kernels in waves (8 per wave slot of the device) */
-    int      cus = 256;
-    int      kp_per_cu = 16;   /* resident waves per CU of k_orientation / k_descriptor (keypoint.hip, kp_fetch) */
+    int      kp_waves = 65536; /* launch size of the keypoint kernels in waves (8 per wave slot of the device) */
     int      det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
     int      desc_rows = 1 << 30;
     int      cand_cap_init = 1 << 20;
@@ -528,9 +526,6 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 /* Pyramid::step2 + prep_features: extrema -> orientation -> scan -> descriptors -> features */
 InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iext2 : c->d_iext; }
 
-/* launch size of the resident-wave keypoint kernels: a multiple of 8 (one work-list head per XCD) */
-int kp_resident(const popsift_hip_ctx* c) { return std::max(c->cus, 8) * std::min(std::max(c->kp_per_cu, 1), 32) / 8 * 8; }
-
 /* counters_cleared: the level-0 launch of this image has zeroed d_ct (submit); re-runs clear it here */
 int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
 {
@@ -548,7 +543,7 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
         SYNC_CHK(c, "grid filter");
     }
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_ORIENTATION));
-    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, kp_resident(c),
+    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->kp_waves,
                                   c->stream));
     SYNC_CHK(c, "k_orientation");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_SCAN));
@@ -557,8 +552,7 @@ int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
                            std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_drec, c->d_feats, c->desc_cap, c->stream));
     SYNC_CHK(c, "k_scan_local / k_scan_apply");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DESCRIPTOR));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_drec, c->d_desc, c->desc_cap,
-                                  c->sc.desc_mode == POPSIFT_HIP_DESC_LOOP ? kp_resident(c) : c->kp_waves,
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_drec, c->d_desc, c->desc_cap, c->kp_waves,
                                   c->stream));
     SYNC_CHK(c, "descriptor kernel");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_COUNT));
@@ -871,7 +865,6 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
             c->kp_waves = std::max(cus, 8) * 32 * 8; /* a multiple of 32 */
-            c->cus = cus;
         }
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
@@ -1392,9 +1385,6 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_FAIL_ALLOC:
         c->fail_alloc_in = std::max(value, 0);
-        return POPSIFT_HIP_OK;
-    case POPSIFT_HIP_DEBUG_KP_PER_CU:
-        c->kp_per_cu = std::min(std::max(value, 1), 32);
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_DESC_ROWS:
         c->desc_rows = c->sc.desc_rows = std::max(value, 4);

@@ -114,7 +114,13 @@ __device__ __forceinline__ float plane_at(const float* pl, int idx)
  * (Tried and dropped, round 2: resident waves pulling positions from work queues in device memory -- one returning
  * atomicAdd per keypoint on 32 padded heads, next position requested ahead of time.  592 us against 505 us for the
  * descriptor kernel, 164 against 106 for orientation: the hardware dispatcher already balances 65536 single-wave
- * workgroups, and it does so without a memory round trip in the wave's in-order load queue.)
+ * workgroups, and it does so without a memory round trip in the wave's in-order load queue.  Round 3 repeated it with
+ * FEWER resident waves -- 8 .. 32 per CU, one counter per XCD, one descriptor / four histograms per fetch -- so that wave
+ * slots, registers and LDS stay free for the other images' bandwidth-bound kernels: at 32 per CU it equals this
+ * distribution (k_descriptor 421 us, 2.90 Gpix/s), at 24 / 16 / 12 / 8 it loses (2.89 / 2.77 / 2.58 / 2.47 Gpix/s), and
+ * the level launches of the other images take as long in the mix as before (107 us against 108 us per octave-0 level,
+ * profiles/r03_timeline_resident16.txt): what slows them beside a descriptor kernel is the shared vector issue, LDS and
+ * L2, not the lack of a free slot.  DESIGN 6.4.)
  */
 #ifndef KP_CHUNK
 #define KP_CHUNK 256
@@ -134,29 +140,6 @@ __device__ __forceinline__ XcdSlice xcd_slice()
     sl.step = (int)(gridDim.x >> 3) * NW;
     return sl;
 }
-
-/*
- * The same distribution for RESIDENT waves (round 3).  k_orientation and k_descriptor are launched with far fewer
- * waves than the device has slots for (ctx.hip: kp_resident), so that wave slots, registers and LDS stay free for the
- * bandwidth-bound kernels of the other images in flight: as 65536 single-wave workgroups they refilled every slot the
- * moment it became free, and a blur tile of another stream (8 waves and 43-67 KB of LDS at once on one CU) found no room
- * until the whole grid had been dispatched -- in the timed loop a 20 us level launch took 117 us on average and three of
- * the four hardware queues stood still while a k_descriptor ran (profiles/r03_bench_quick_timeline_before.txt).
- * A static stride over keypoints whose cost spreads 1 : 4 leaves the long ones for the end (round 2: 729 us at 4096
- * waves), so the resident waves take their positions from a counter per XCD, KP_FETCH at a time -- one returning
- * atomic per KP_FETCH keypoints (~100 us of work), issued when the wave has nothing else in flight.  Position s of
- * XCD x is the element XcdSlice::index() gives, so the locality argument above is unchanged.
- */
-constexpr int KP_FETCH = 4; /* divides KP_CHUNK: a fetch never straddles two chunks */
-static_assert(KP_CHUNK % KP_FETCH == 0, "a fetch stays inside one chunk");
-__device__ __forceinline__ int kp_fetch(int* head, int lane)
-{
-    int s0 = 0;
-    if (lane == 0) s0 = atomicAdd(head, KP_FETCH);
-    return __builtin_amdgcn_readfirstlane(s0);
-}
-__device__ __forceinline__ bool kp_more(int s0, int total) { return (s0 / KP_CHUNK) * 8 * KP_CHUNK < total; }
-__device__ __forceinline__ int kp_index(int s, int x) { return ((s / KP_CHUNK) * 8 + x) * KP_CHUNK + (s % KP_CHUNK); }
 
 /* clamped extrema counts -> exclusive prefix (uniform, <= 20 entries) */
 __device__ __forceinline__ int ext_prefix(const Counters* ct, const SiftConsts& sc, int n_oct, int* ps)
@@ -259,9 +242,10 @@ __device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
 __device__ __forceinline__ float atan2_bins(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float       r = mn * __builtin_amdgcn_rcpf(mx);
-    r = (mx == 0.0f) ? 0.0f : r;
+    /* the larger magnitude is kept off zero inside the v_max3 (0 / 1e-30 = 0: the same result as the test for a zero
+     * gradient it replaces), the sign of y is copied with one v_bfi (t >= 0; y = -0 gives -t, the same angle mod 8) */
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+    const float r = mn * __builtin_amdgcn_rcpf(mx);
     const float s = r * r;
     float       p = fmaf(-0.01492126751691103f, s, 0.06703268736600876f);
     p = fmaf(p, s, -0.14823880791664124f);
@@ -271,7 +255,7 @@ __device__ __forceinline__ float atan2_bins(float y, float x)
     float t = p * r;
     t = (ay > ax) ? 2.0f - t : t;
     t = (x < 0.0f) ? 4.0f - t : t;
-    return (y < 0.0f) ? -t : t;
+    return copysignf(t, y);
 }
 
 /* The same with a degree-9 polynomial (max error 1.5e-5 bins = 1.2e-5 rad, fitted offline as a minimax problem) for the
@@ -327,11 +311,8 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
     __syncthreads();
     const int total = min(ps[n_oct], hist_cap);
 
-    static_assert(KP_NW == 1, "resident waves: one wave per workgroup");
-    const int xcd = blockIdx.x & 7;
-    for (int s0 = kp_fetch(&ct->kpq[xcd].n, lane); kp_more(s0, total); s0 = kp_fetch(&ct->kpq[xcd].n, lane))
-    for (int sk = 0; sk < KP_FETCH; sk++) {
-        const int g = kp_index(s0 + sk, xcd);
+    for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
+        const int g = sl.index();
         if (g >= total) continue;
         int o = 0;
         while (o + 1 < n_oct && g >= ps[o + 1]) o++;
@@ -348,7 +329,7 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         const float x = uniformf(ie.xpos), y = uniformf(ie.ypos), sig = uniformf(ie.sigma);
         const float sigw = ORI_WINFACTOR * sig;
         const int   rad = (int)roundf(3.0f * sigw);
-        const float factor = -0.5f / (sigw * sigw);
+        const float factor2 = (-0.5f / (sigw * sigw)) * 1.4426950408889634f; /* in powers of two */
         const int   sq_thres = rad * rad;
         const int   xmin = max(1, (int)roundf(x) - rad);
         const int   xmax = min(w - 2, (int)roundf(x) + rad);
@@ -375,8 +356,9 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
              * comparison with rad^2 and the product with `factor` give what the int round trip gives) */
             const float sq_dist = truncf(dx * dx + dy * dy);
             if (live && sq_dist <= (float)sq_thres) {
-                const float grad = __builtin_amdgcn_sqrtf(gdx * gdx + gdy * gdy); /* hypotf */
-                const float weight = grad * __expf(sq_dist * factor);
+                /* hypotf * expf(sq_dist * factor) * 2^20 (the fixed-point scale of to_fix): the scale and log2(e) go into
+                 * the exponent, so the window weight is one FMA and one v_exp */
+                const float wfix = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy)) * __builtin_amdgcn_exp2f(fmaf(sq_dist, factor2, 20.0f));
                 /* The bin is a HARD decision, so the angle needs libm-grade accuracy -- but only when it lies next to a
                  * bin edge: the cheap atan2 (the descriptor's one-reciprocal degree-11 polynomial in units of pi / 4:
                  * error < 1.7e-6 rad = 1e-5 of these bins) decides every sample farther than 1e-4 bins from an edge
@@ -394,7 +376,7 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
                 /* roundf(fb) for fb >= 0: the floor, plus one from the half on (fb - floor is exact) */
                 int bidx = (int)fl + (fr >= 0.5f ? 1 : 0);
                 bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
-                if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], to_fix(weight));
+                if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], (fix64)(unsigned int)wfix);
             }
         };
         /* two register sets take turns as "being binned" and "in flight", as in k_descriptor (unrolled by two, so no
@@ -815,10 +797,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
     /* rows per pass: DESC_MAXROWS, or fewer when a test asks for it (popsift_hip_debug_set DESC_ROWS) */
     const int     maxrows = min(max(sc.desc_rows, 4), DESC_MAXROWS);
 
-    const int xcd = blockIdx.x & 7;
-    for (int s0 = kp_fetch(&ct->kpq[8 + xcd].n, lane); kp_more(s0, total); s0 = kp_fetch(&ct->kpq[8 + xcd].n, lane))
-    for (int sk = 0; sk < KP_FETCH; sk++) {
-        const int d = kp_index(s0 + sk, xcd);
+    for (XcdSlice sl = xcd_slice<KP_NW>(); sl.more(total); sl.s += sl.step) {
+        const int d = sl.index();
         if (d >= total) continue;
         /* everything about the descriptor is wave-uniform and was worked out by k_scan_apply (DescRec): three 16-byte
          * loads of one address, moved to scalar registers (the taps become scalar-base + 32-bit-offset loads) */
@@ -992,7 +972,11 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     w01.x = 1.0f - do0;
                     w01.y = do0;
                     /* the four cell weights as two packed products */
+#ifndef DESC_PK
+                    const v2f p0 = {wxx.x * wy0, wxx.y * wy0}, p1 = {wxx.x * wy1, wxx.y * wy1};
+#else
                     const v2f p0 = wxx * (v2f){wy0, wy0}, p1 = wxx * (v2f){wy1, wy1};
+#endif
                     /* byte addresses of the four words (a word is only touched when its weight is positive, and then
                      * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped): one base, the slot of the even and of the odd
                      * cell column, immediate offsets for the neighbours */
@@ -1005,11 +989,16 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
                     const unsigned int e0 = cb + s0;
                     const unsigned int e1 = (s0 ^ 32u) + cb;
 /* ISA: atomics */
+#ifndef DESC_PK
+#define DESC_PKFMA(W, G) ((v2f){fmaf((W).x, (G), 0.5f), fmaf((W).y, (G), 0.5f)})
+#else
+#define DESC_PKFMA(W, G) __builtin_elementwise_fma((W), (v2f){(G), (G)}, (v2f){0.5f, 0.5f})
+#endif
 #define PS_CELL(ADDR, WGT)                                                                              \
     {                                                                                                   \
         const float wgt = (WGT);                                                                        \
         if (wgt > 0.0f) {                                                                               \
-            const v2f f = __builtin_elementwise_fma(w01, (v2f){wgt, wgt}, (v2f){0.5f, 0.5f});           \
+            const v2f f = DESC_PKFMA(w01, wgt);                                                         \
             __hip_atomic_fetch_add((lds_fix64*)(size_t)(ADDR), ((fix64)(unsigned int)f.y << 32) | (fix64)(unsigned int)f.x, \
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                      \
         }                                                                                               \

@@ -103,12 +103,6 @@ struct Counters {
         int n;
         int pad[31];
     } qcnt[64];
-    /* work-list heads of the resident keypoint waves (keypoint.hip, kp_fetch): [0..7] k_orientation, [8..15]
-     * k_descriptor, one per XCD, each on a cache line of its own */
-    struct {
-        int n;
-        int pad[31];
-    } kpq[16];
 };
 #define DET_SUBQ 64
 

@@ -247,16 +247,18 @@ def test_two_workers_on_one_card_through_matching_mode(tmp_path, gpu_hip):
     db, _ = sb.download()
     want = sa.match(sb)
     ha, hb = _hash_rows(da), _hash_rows(db)
-    assert len(set(ha.tolist())) == na, "duplicate left descriptors: rows cannot be aligned by content"
+    # a few descriptors occur twice (two orientations of one keypoint a hair apart): such rows have the same match by
+    # construction (the search sees only the descriptor bytes), so any row of that content stands for all of them
     row_of = {int(h): i for i, h in enumerate(ha)}
-    seen = set()
+    assert len(row_of) >= na - na // 500
+    seen = []
     for hl, hbest, hsecond, accept, dbest, dsecond in got:
         i = row_of[int(hl, 16)]          # KeyError: the host API extracted a descriptor the C-ABI run does not have
-        seen.add(i)
+        seen.append(int(hl, 16))
         w = want[i]
         assert int(hbest, 16) == int(hb[w["best"]]) and int(hsecond, 16) == int(hb[w["second"]]), "row %d: best / second differ" % i
         assert int(accept) == int(w["accept"]), "row %d: accept differs" % i
         assert np.float32(dbest) == w["dist_best"] and np.float32(dsecond) == w["dist_second"], "row %d: distances differ" % i
-    assert len(seen) == na
+    assert sorted(seen) == sorted(int(h) for h in ha)      # the same multiset of left descriptors
     assert acc == int(want["accept"].sum())
     assert acc > 50, "the two views must share matches (zoom 1.12, 10 degrees)"

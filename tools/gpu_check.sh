@@ -24,18 +24,6 @@ run_one() {
   (cd $R && timeout -k 10 300 python3 bench.py --quick --steps 10 --warmup 2 2>&1 | tail -1)
 }
 echo "== product (pytest rc=${TEST_RC:-skipped})"; unset POPSIFT_HIP_LIB; run_one main
-if [ -n "$KP_SWEEP" ]; then
-  for k in $KP_SWEEP; do
-    echo "== resident keypoint waves per CU: $k"
-    export PROF_KP_PER_CU=$k
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/chk_k$k -- python3 $R/tools/prof_run.py 5 > $OUT/k$k.log 2>&1 || exit 1
-    python3 $R/tools/kstats.py /tmp/chk_k$k | grep -E "k_descriptor|k_orientation"
-    grep -E "ms$" $OUT/k$k.log | tail -1
-    rm -rf /tmp/chk_k$k
-    (cd $R && timeout -k 10 300 python3 bench.py --quick --steps 10 --warmup 2 --kp-per-cu $k 2>&1 | tail -1)
-  done
-  unset PROF_KP_PER_CU
-fi
 if [ "$1" = "variants" ] || [ "$2" = "variants" ]; then
   for so in $R/build_variants/v*.so; do
     n=$(basename $so .so)

@@ -139,10 +139,11 @@ def main():
           (kernel, hdr, depth, len(member), samples, " ".join(extra) or "(Makefile)"))
     print("# " + "  ".join(x.strip("; ").strip() for x in vg))
     tot_v = kinds["valu"] + kinds["valu_quarter"]
-    print("per sample: VALU %.1f (of which quarter-rate %.1f => %.1f full-rate issue slots)  SALU %.1f  LDS %.1f  VMEM %.1f  waits/nops %.1f"
-          % (tot_v / samples, kinds["valu_quarter"] / samples, (kinds["valu"] + 4 * kinds["valu_quarter"]) / samples,
+    # issue cost on gfx950 (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): transcendentals 8 cycles against 4
+    print("per sample: VALU %.1f (of which transcendental / 32-bit multiply %.1f => %.1f plain-VALU issue slots)  SALU %.1f  LDS %.1f  VMEM %.1f  waits/nops %.1f"
+          % (tot_v / samples, kinds["valu_quarter"] / samples, (kinds["valu"] + 2 * kinds["valu_quarter"]) / samples,
              kinds["salu"] / samples, kinds["lds"] / samples, kinds["vmem"] / samples, kinds["wait_nop"] / samples))
-    print("\n%-22s %8s %8s %8s %8s %8s" % ("group (per sample)", "VALU", "quarter", "SALU", "LDS", "VMEM"))
+    print("\n%-22s %8s %8s %8s %8s %8s" % ("group (per sample)", "VALU", "slow", "SALU", "LDS", "VMEM"))
     for g in sorted(bygroup, key=lambda g: -(bygroup[g]["valu"] + bygroup[g]["valu_quarter"])):
         c = bygroup[g]
         print("%-22s %8.1f %8.1f %8.1f %8.1f %8.1f" % (g, (c["valu"] + c["valu_quarter"]) / samples, c["valu_quarter"] / samples,

@@ -20,6 +20,7 @@ cat $OUT/bench_traced.json
 python3 $R/tools/mix_timeline.py $RAW/trace > $OUT/timeline.txt 2>&1
 python3 $R/tools/kstats.py $RAW/trace > $OUT/kernel_stats.txt 2>&1
 head -30 $OUT/timeline.txt
+[ -n "$NOPMC" ] && exit 0
 timeout -k 10 500 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $RAW/pmc -- python3 $R/bench.py --quick --steps 2 --warmup 1 > $OUT/bench_pmc.json 2> $RAW/pmc.err
 echo "pmc rc=$?"
 python3 $R/tools/pmc.py $RAW/pmc > $OUT/pmc.txt 2>&1

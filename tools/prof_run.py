@@ -12,7 +12,5 @@ img = synth(2, W, H)
 import json
 kw = json.loads(os.environ.get("PROF_KW", "{}"))
 ctx = hip.Context(hip.default_params(**kw))
-if os.environ.get("PROF_KP_PER_CU"):
-    ctx.debug_set(hip.DEBUG_KP_PER_CU, int(os.environ["PROF_KP_PER_CU"]))
 for i in range(n):
     ctx.submit(img); c = ctx.wait(); print(c, "%.3f ms" % ctx.report().ms_device, flush=True)

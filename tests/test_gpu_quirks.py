@@ -32,7 +32,14 @@ def test_reference_quirks_on_the_gpu(oracle_mod, gpu_hip, name, case, kw, nori):
     a, b = fo[0], fh[0]
     assert bits(a["xpos"]) == bits(b["xpos"]) and bits(a["ypos"]) == bits(b["ypos"])
     assert a["num_ori"] == b["num_ori"] and (nori is None or a["num_ori"] == nori)
-    np.testing.assert_allclose(b["orientation"], a["orientation"], atol=2e-6)
+    # The crafted planes are mirror-symmetric, so two of a keypoint's histogram peaks can be equal up to the rounding of
+    # the sums (the reference's float atomicAdd arrives in no fixed order, s_orientation.cu:136): the orientations are
+    # compared as a SET, and each descriptor with the descriptor of the same orientation.
+    n = int(a["num_ori"])
+    oa, ob = np.argsort(a["orientation"][:n], kind="stable"), np.argsort(b["orientation"][:n], kind="stable")
+    np.testing.assert_allclose(b["orientation"][:n][ob], a["orientation"][:n][oa], atol=2e-6)
     assert do.shape == dh.shape and np.all(np.isfinite(dh))
-    rel = np.linalg.norm(do - dh, axis=1) / np.maximum(np.linalg.norm(do, axis=1), 1e-20)
+    da = np.stack([do[a["desc_idx"][k]] for k in oa])
+    db = np.stack([dh[b["desc_idx"][k]] for k in ob])
+    rel = np.linalg.norm(da - db, axis=1) / np.maximum(np.linalg.norm(da, axis=1), 1e-20)
     assert rel.max() < 1e-3

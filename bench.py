@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per step per GPU (one step = one batch)")
-    ap.add_argument("--contexts", type=int, default=16, help="extraction contexts (images in flight) per GPU")
+    ap.add_argument("--contexts", type=int, default=16, help="extraction contexts (streams) per GPU")
+    ap.add_argument("--launch-batch", type=int, default=1,
+                    help="images a context extracts per submit (popsift_hip_submit_batch: every kernel launched once for all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="timed loop only: no roofline / host-to-host / CPU legs (A/B runs)")
     ap.add_argument("--only-roofline", action="store_true",
@@ -91,8 +93,8 @@ class Workers:
     (images i, i + C, i + 2C, ... of the step), which the context extracts back to back; the step ends when
     every context has finished its last image."""
 
-    def __init__(self, ctxs, ptrs):
-        self.ctxs, self.ptrs = ctxs, ptrs
+    def __init__(self, ctxs, ptrs, launch_batch=1):
+        self.ctxs, self.ptrs, self.lb = ctxs, ptrs, max(1, launch_batch)
         self.n = len(ctxs)
         self.go = threading.Barrier(self.n + 1)
         self.done = threading.Barrier(self.n + 1)
@@ -110,11 +112,19 @@ class Workers:
             if self.stop:
                 return
             f = d = 0
-            for p in self.ptrs[i::self.n]:
-                ctx.submit_dev(p, W, H, W)
-                nf, nd = ctx.wait()
-                f += nf
-                d += nd
+            mine = self.ptrs[i::self.n]
+            if self.lb == 1:
+                for p in mine:
+                    ctx.submit_dev(p, W, H, W)
+                    nf, nd = ctx.wait()
+                    f += nf
+                    d += nd
+            else:
+                for k in range(0, len(mine), self.lb):
+                    ctx.submit_batch_dev(mine[k:k + self.lb], W, H, W)
+                    for nf, nd in ctx.wait_batch():
+                        f += nf
+                        d += nd
             self.feats[i], self.descs[i] = f, d
             self.done.wait()
 
@@ -217,7 +227,7 @@ def main():
     ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
     C = max(1, min(args.contexts, B))
     ctxs = [hip.Context(hip.default_params(), device=local_rank) for _ in range(C)]
-    workers = Workers(ctxs, ptrs)
+    workers = Workers(ctxs, ptrs, args.launch_batch)
 
     def barrier():
         torch.cuda.synchronize()

@@ -25,6 +25,7 @@ extern "C" {
 
 #define POPSIFT_HIP_MAX_OCTAVES 20 /* sift_conf.h:13 MAX_OCTAVES */
 #define POPSIFT_HIP_MAX_LEVELS 12  /* sift_constants.h:35 GAUSS_LEVELS */
+#define POPSIFT_HIP_MAX_BATCH 16   /* images of one size a context extracts per submit (popsift_hip_submit_batch) */
 #define POPSIFT_HIP_GAUSS_ALIGN 32 /* sift_constants.h:34 GAUSS_ALIGN */
 #define POPSIFT_HIP_ORI_MAX 4      /* sift_constants.h:51 ORIENTATION_MAX_COUNT */
 
@@ -188,6 +189,26 @@ int popsift_hip_submit_pinned_f32(popsift_hip_ctx* ctx, const float* img, int w,
 /* Same, image already resident in this device's memory (bench "inputs in HBM"). */
 int popsift_hip_submit_dev_u8(popsift_hip_ctx* ctx, const void* d_img, int w, int h, int pitch);
 int popsift_hip_submit_dev_f32(popsift_hip_ctx* ctx, const void* d_img, int w, int h, int pitch);
+
+/*
+ * Several images of ONE size per submit (round 3).  The reference's demo enqueues all its images and then collects all
+ * the results (src/application/main.cpp:304-326) while its pipeline still extracts them one by one
+ * (popsift.cpp:139-213); here up to POPSIFT_HIP_MAX_BATCH images go through the per-image launch sequence TOGETHER --
+ * every kernel is launched once for the whole batch, image index in blockIdx.y -- so the latency-bound launches of the
+ * small octaves, refinement and the scans are paid once per batch.  Every image has its own planes, lists and result
+ * slabs: its results are bit-identical to a submit of its own, whatever it is batched with
+ * (tests/test_gpu_batch.py).  kind says where the images lie and what they hold; pointers, w, h, pitch as for the
+ * single-image calls above, which are batches of one.  The slots of a context are allocated on first use and kept.
+ */
+enum { POPSIFT_HIP_IMG_HOST_U8 = 0, POPSIFT_HIP_IMG_HOST_F32 = 1, POPSIFT_HIP_IMG_DEV_U8 = 2, POPSIFT_HIP_IMG_DEV_F32 = 3,
+       POPSIFT_HIP_IMG_PINNED_U8 = 4, POPSIFT_HIP_IMG_PINNED_F32 = 5 };
+int popsift_hip_submit_batch(popsift_hip_ctx* ctx, const void* const* imgs, int n, int kind, int w, int h, int pitch);
+/* blocks until the batch is finished; n_features / n_descriptors: arrays of at least *n_images (= the n submitted) */
+int popsift_hip_wait_batch(popsift_hip_ctx* ctx, int* n_images, int* n_features, int* n_descriptors);
+/* results of image k of the finished batch (popsift_hip_fetch / popsift_hip_results_dev are k = 0) */
+int popsift_hip_fetch_item(popsift_hip_ctx* ctx, int k, popsift_hip_feature* feats, size_t feats_cap, float* desc,
+                           size_t desc_cap);
+int popsift_hip_results_dev_item(popsift_hip_ctx* ctx, int k, const void** d_feats, const void** d_desc);
 
 /* Replaces the counter read-back of Pyramid::get_descriptors
  * (sift_pyramid.cu:281-294): blocks until the submitted image is finished and

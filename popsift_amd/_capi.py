@@ -94,6 +94,10 @@ SYMBOLS = [
     ("popsift_hip_submit_dev_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("popsift_hip_submit_pinned_u8", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("popsift_hip_submit_pinned_f32", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_submit_batch", C.c_int, [_vp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("popsift_hip_wait_batch", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("popsift_hip_fetch_item", C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
+    ("popsift_hip_results_dev_item", C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("popsift_hip_wait", C.c_int, [_vp, _ip, _ip]),
     ("popsift_hip_fetch", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("popsift_hip_fetch_begin", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
@@ -122,6 +126,8 @@ SYMBOLS = [
 MATCH_AUTO, MATCH_EXACT, MATCH_SCREEN = 0, 1, 2
 STAGES = ("pyramid", "detect", "refine", "orientation", "scan", "descriptor")
 DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC, DEBUG_DESC_ROWS = 1, 2, 3, 4, 5
+MAX_BATCH = 16
+IMG_HOST_U8, IMG_HOST_F32, IMG_DEV_U8, IMG_DEV_F32, IMG_PINNED_U8, IMG_PINNED_F32 = range(6)
 
 _lib = None
 
@@ -343,6 +349,45 @@ class Context:
         fn = lib().popsift_hip_submit_dev_f32 if is_f32 else lib().popsift_hip_submit_dev_u8
         self._chk(fn(self._h, ptr, w, h, pitch), "popsift_hip_submit_dev")
         return self
+
+    def submit_batch(self, imgs):
+        """popsift_hip_submit_batch: several host images of one size and dtype, extracted together"""
+        imgs = [np.ascontiguousarray(im) for im in imgs]
+        h, w = imgs[0].shape
+        if any(im.shape != (h, w) or im.dtype != imgs[0].dtype for im in imgs):
+            raise ValueError("the images of a batch share one size and dtype")
+        if imgs[0].dtype == np.uint8:
+            kind = IMG_HOST_U8
+        elif imgs[0].dtype == np.float32:
+            kind = IMG_HOST_F32
+        else:
+            raise TypeError("uint8 or float32 images expected, got %s" % imgs[0].dtype)
+        arr = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+        self._chk(lib().popsift_hip_submit_batch(self._h, arr, len(imgs), kind, w, h, w), "popsift_hip_submit_batch")
+        return self
+
+    def submit_batch_dev(self, ptrs, w, h, pitch, is_f32=False):
+        """the same for images resident in this device's memory (ptrs: device addresses)"""
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        self._chk(lib().popsift_hip_submit_batch(self._h, arr, len(ptrs), IMG_DEV_F32 if is_f32 else IMG_DEV_U8, w, h, pitch),
+                  "popsift_hip_submit_batch")
+        return self
+
+    def wait_batch(self):
+        """-> [(features, descriptors)] per image of the batch"""
+        n = C.c_int()
+        nf = (C.c_int * MAX_BATCH)()
+        nd = (C.c_int * MAX_BATCH)()
+        self._chk(lib().popsift_hip_wait_batch(self._h, C.byref(n), nf, nd), "popsift_hip_wait_batch")
+        return [(nf[k], nd[k]) for k in range(n.value)]
+
+    def fetch_item(self, k):
+        nf, nd = self.wait_batch()[k]
+        feats = np.zeros(nf, FEATURE_DTYPE)
+        desc = np.zeros((nd, 128), np.float32)
+        self._chk(lib().popsift_hip_fetch_item(self._h, k, feats.ctypes.data, nf, desc.ctypes.data, nd * 128),
+                  "popsift_hip_fetch_item")
+        return feats, desc
 
     def wait(self):
         a, b = C.c_int(), C.c_int()

@@ -51,6 +51,37 @@ struct EventPair {
 
 }  // namespace
 
+/* Device memory of ONE image of a batch (sift_types.h, Slot): what a single-image context owned.  Grow-only. */
+struct ImageSlot {
+    void*   d_input = nullptr;
+    size_t  input_cap = 0;
+    void*   h_input = nullptr; /* pinned staging: submit() copies the caller's image before returning */
+    size_t  h_input_cap = 0;
+    float*  d_arena = nullptr;
+    size_t  arena_cap = 0; /* floats */
+    InitExt* d_iext = nullptr;
+    InitExt* d_iext2 = nullptr;      /* grid filter output (filter enabled only) */
+    FilterState* d_fstate = nullptr;
+    int*     d_fhist = nullptr;
+    Ext*     d_ext = nullptr;
+    float*   d_ohist = nullptr; /* raw orientation histograms, 36 floats per extremum (k_orientation -> k_scan_local) */
+    size_t   ohist_cap = 0;     /* extrema */
+    popsift_hip_feature* d_feats = nullptr;
+    size_t   iext_cap = 0, iext2_cap = 0, extrec_cap = 0, feats_cap = 0;
+    int*     d_map = nullptr;
+    float2*  d_rot = nullptr; /* (cos, sin) of every descriptor's orientation, correctly rounded (k_scan_apply) */
+    DescRec* d_drec = nullptr; /* per-descriptor constants of the loop descriptor (k_scan_apply -> k_descriptor) */
+    float*   d_desc = nullptr;
+    int      desc_cap = 0;
+    int2*    d_cand = nullptr;
+    int      cand_cap = 0;
+    int*     d_partial = nullptr; /* one partial sum per scan chunk */
+    size_t   partial_cap = 0;
+    int*     d_ovf = nullptr;     /* detection strips handed to the slow pass */
+    size_t   ovf_cap = 0;
+    bool     sized = false;       /* the buffers fit the context's current geometry */
+};
+
 struct popsift_hip_ctx {
     int                device = 0;
     popsift_hip_params p{};
@@ -61,41 +92,27 @@ struct popsift_hip_ctx {
     hipEvent_t         ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t         ev_stage[POPSIFT_HIP_STAGE_COUNT + 1] = {}; /* profile mode 2: boundaries of the stages */
 
-    /* image geometry */
+    /* image geometry (one for all images of a batch) */
     int  in_w = 0, in_h = 0;
     int  frozen_octaves = -1;
-    bool have_image = false, finished = false, fetched_counts = false;
+    bool have_image = false, finished = false;
+    int  nb = 1; /* images of the submitted batch */
 
-    /* device memory (grow-only) */
-    void*   d_input = nullptr;
-    size_t  input_cap = 0;
-    void*   h_input = nullptr; /* pinned staging: submit() copies the caller's image before returning */
-    size_t  h_input_cap = 0;
-    float*  d_arena = nullptr;
-    size_t  arena_cap = 0; /* floats */
-    PyrDesc pd{};
-    int      kp_waves = 65536; /* launch size of the keypoint kernels in waves (8 per wave slot of the device) */
-    int      det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
-    int      desc_rows = 1 << 30;
-    int      cand_cap_init = 1 << 20;
-    int      ohist_cap_init = 0;
-    InitExt* d_iext = nullptr;
-    InitExt* d_iext2 = nullptr;      /* grid filter output (filter enabled only) */
-    FilterState* d_fstate = nullptr;
-    int*     d_fhist = nullptr;
-    Ext*     d_ext = nullptr;
-    float*   d_ohist = nullptr; /* raw orientation histograms, 36 floats per extremum (k_orientation -> k_scan_local) */
-    size_t   ohist_cap = 0;     /* extrema */
-    popsift_hip_feature* d_feats = nullptr;
-    size_t   ext_cap = 0; /* entries every one of d_iext/d_ext/d_feats(/d_iext2) holds */
-    size_t   iext_cap = 0, iext2_cap = 0, extrec_cap = 0, feats_cap = 0;
-    int*     d_map = nullptr;
-    float2*  d_rot = nullptr; /* (cos, sin) of every descriptor's orientation, correctly rounded (k_scan_apply) */
-    DescRec* d_drec = nullptr; /* per-descriptor constants of the loop descriptor (k_scan_apply -> k_descriptor) */
-    float*   d_desc = nullptr;
-    int      desc_cap = 0;
-    /* second result slab (popsift_hip_fetch_begin): the download of image i reads one slab on copy_stream while the
-     * kernels of image i+1 write the other.  Invariant: alt caps <= the current slab's; fetch_begin equalises and swaps */
+    /* one slot per image of a batch; a plain submit uses slot 0 */
+    ImageSlot slot[PS_MAX_BATCH];
+    BatchDesc bd{}; /* the kernels' view of the slots in use (a kernel argument, passed by value) */
+    PyrDesc   pd{};
+    int       kp_waves = 65536; /* launch size of the keypoint kernels in waves (8 per wave slot of the device) */
+    int       det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
+    int       desc_rows = 1 << 30;
+    int       cand_cap_init = 1 << 20;
+    int       ohist_cap_init = 0;
+    size_t    ext_cap = 0; /* entries every one of d_iext/d_ext/d_feats(/d_iext2) of the sized slots holds */
+    /* capacities the kernels are told: the smallest over the slots of the batch (refresh_caps) */
+    int       cand_cap = 0, desc_cap = 0;
+    size_t    ohist_cap = 0;
+    /* second result slab of slot 0 (popsift_hip_fetch_begin): the download of image i reads one slab on copy_stream while
+     * the kernels of image i+1 write the other.  Invariant: alt caps <= the current slab's; fetch_begin equalises and swaps */
     popsift_hip_feature* alt_feats = nullptr;
     size_t   alt_feats_cap = 0;
     float*   alt_desc = nullptr;
@@ -103,16 +120,11 @@ struct popsift_hip_ctx {
     hipStream_t copy_stream = nullptr;
     bool     copy_pending = false;  /* a fetch_begin download has not been waited for */
     bool     results_moved = false; /* the finished image's results went to fetch_begin: the current slab is stale */
-    Counters* d_ct = nullptr;
-    Counters* h_ct = nullptr; /* pinned */
+    Counters* d_ct = nullptr; /* PS_MAX_BATCH counter blocks, one per slot */
+    Counters* h_ct = nullptr; /* pinned mirror */
     PyrDesc*  d_pd = nullptr; /* device copy of pd (kernels index octaves dynamically) */
     PyrDesc*  h_pd = nullptr; /* pinned staging for d_pd */
-    int2*     d_cand = nullptr;
-    int       cand_cap = 0;
-    int*      d_partial = nullptr; /* one partial sum per scan chunk */
-    int*      d_ovf = nullptr;     /* detection strips handed to the slow pass */
-    size_t    ovf_cap = 0;
-    size_t    partial_cap = 0;
+    int       n_feat[PS_MAX_BATCH] = {}, n_desc[PS_MAX_BATCH] = {}; /* results of the finished batch */
 
     /* profiling */
     int                    fail_alloc_in = 0; /* test hook (popsift_hip_debug_fail_alloc): the n-th device allocation from now fails */
@@ -258,147 +270,213 @@ int grow(popsift_hip_ctx* c, T** ptr, size_t* cap, size_t need)
     return 0;
 }
 
+/* the capacities the kernels are told = the smallest over the slots of the batch, and the kernels' slot table */
+void refresh_caps(popsift_hip_ctx* c)
+{
+    int    cand = 1 << 30, desc = 1 << 30;
+    size_t hist = (size_t)1 << 40;
+    for (int k = 0; k < c->nb; k++) {
+        const ImageSlot& s = c->slot[k];
+        cand = std::min(cand, s.cand_cap);
+        desc = std::min(desc, s.desc_cap);
+        hist = std::min(hist, s.ohist_cap);
+        Slot& v = c->bd.s[k];
+        v.arena = s.d_arena;
+        v.ct = c->d_ct + k;
+        v.cand = s.d_cand;
+        v.ovf = s.d_ovf;
+        v.iext = s.d_iext;
+        v.iext2 = s.d_iext2;
+        v.fstate = s.d_fstate;
+        v.fhist = s.d_fhist;
+        v.ohist = s.d_ohist;
+        v.ext = s.d_ext;
+        v.partial = s.d_partial;
+        v.map = s.d_map;
+        v.rot = s.d_rot;
+        v.drec = s.d_drec;
+        v.feats = s.d_feats;
+        v.desc = s.d_desc;
+    }
+    c->cand_cap = cand;
+    c->desc_cap = desc;
+    c->ohist_cap = hist;
+}
+
+int slot_desc_cap(popsift_hip_ctx* c, ImageSlot& s, int need)
+{
+    if (need <= s.desc_cap) return 0;
+    if (s.d_desc) HIP_TRY(c, hipFree(s.d_desc));
+    if (s.d_map) HIP_TRY(c, hipFree(s.d_map));
+    if (s.d_rot) HIP_TRY(c, hipFree(s.d_rot));
+    if (s.d_drec) HIP_TRY(c, hipFree(s.d_drec));
+    s.d_desc = nullptr;
+    s.d_map = nullptr;
+    s.d_rot = nullptr;
+    s.d_drec = nullptr;
+    s.desc_cap = 0;
+    HIP_TRY(c, ctx_malloc(c, (void**)&s.d_desc, (size_t)need * 128 * sizeof(float)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&s.d_map, (size_t)need * sizeof(int)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&s.d_rot, (size_t)need * sizeof(float2)));
+    HIP_TRY(c, ctx_malloc(c, (void**)&s.d_drec, (size_t)need * sizeof(DescRec)));
+    s.desc_cap = need;
+    return 0;
+}
+
+int slot_ohist_cap(popsift_hip_ctx* c, ImageSlot& s, size_t need)
+{
+    if (need <= s.ohist_cap) return 0;
+    if (s.d_ohist) HIP_TRY(c, hipFree(s.d_ohist));
+    s.d_ohist = nullptr;
+    s.ohist_cap = 0;
+    HIP_TRY(c, ctx_malloc(c, (void**)&s.d_ohist, need * PS_ORI_NBINS * sizeof(float)));
+    s.ohist_cap = need;
+    return 0;
+}
+
+int slot_cand_cap(popsift_hip_ctx* c, ImageSlot& s, int need)
+{
+    if (need <= s.cand_cap) return 0;
+    if (s.d_cand) HIP_TRY(c, hipFree(s.d_cand));
+    s.d_cand = nullptr;
+    s.cand_cap = 0;
+    HIP_TRY(c, ctx_malloc(c, (void**)&s.d_cand, (size_t)need * sizeof(int2)));
+    s.cand_cap = need;
+    return 0;
+}
+
+/* grow a list of every slot of the batch; the kernels' capacities follow whatever the outcome */
 int ensure_desc_cap(popsift_hip_ctx* c, int need)
 {
-    if (need <= c->desc_cap) return 0;
-    if (c->d_desc) HIP_TRY(c, hipFree(c->d_desc));
-    if (c->d_map) HIP_TRY(c, hipFree(c->d_map));
-    if (c->d_rot) HIP_TRY(c, hipFree(c->d_rot));
-    if (c->d_drec) HIP_TRY(c, hipFree(c->d_drec));
-    c->d_desc = nullptr;
-    c->d_map = nullptr;
-    c->d_rot = nullptr;
-    c->d_drec = nullptr;
-    c->desc_cap = 0;
-    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_desc, (size_t)need * 128 * sizeof(float)));
-    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_map, (size_t)need * sizeof(int)));
-    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_rot, (size_t)need * sizeof(float2)));
-    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_drec, (size_t)need * sizeof(DescRec)));
-    c->desc_cap = need;
-    return 0;
+    int rc = 0;
+    for (int k = 0; k < c->nb && !rc; k++) rc = slot_desc_cap(c, c->slot[k], need);
+    refresh_caps(c);
+    return rc;
 }
-
 int ensure_ohist_cap(popsift_hip_ctx* c, size_t need)
 {
-    if (need <= c->ohist_cap) return 0;
-    if (c->d_ohist) HIP_TRY(c, hipFree(c->d_ohist));
-    c->d_ohist = nullptr;
-    c->ohist_cap = 0;
-    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_ohist, need * PS_ORI_NBINS * sizeof(float)));
-    c->ohist_cap = need;
-    return 0;
+    int rc = 0;
+    for (int k = 0; k < c->nb && !rc; k++) rc = slot_ohist_cap(c, c->slot[k], need);
+    refresh_caps(c);
+    return rc;
 }
-
 int ensure_cand_cap(popsift_hip_ctx* c, int need)
 {
-    if (need <= c->cand_cap) return 0;
-    if (c->d_cand) HIP_TRY(c, hipFree(c->d_cand));
-    c->d_cand = nullptr;
-    c->cand_cap = 0;
-    HIP_TRY(c, ctx_malloc(c, (void**)&c->d_cand, (size_t)need * sizeof(int2)));
-    c->cand_cap = need;
-    return 0;
+    int rc = 0;
+    for (int k = 0; k < c->nb && !rc; k++) rc = slot_cand_cap(c, c->slot[k], need);
+    refresh_caps(c);
+    return rc;
 }
 
-/* Pyramid::Pyramid / resetDimensions: sizes for this image, grow-only arena.
+/* Pyramid::Pyramid / resetDimensions: sizes for this image size and batch, grow-only buffers.
  * Failure-safe: the context forgets its geometry before anything is freed and commits the new one only after every
  * allocation and the upload of the device copy have been issued, so a submit after a failed one (ERR_OOM is a
  * recoverable status of this ABI) never finds sizes that describe buffers which no longer exist. */
-int prepare_geometry(popsift_hip_ctx* c, int w, int h)
+int prepare_geometry(popsift_hip_ctx* c, int w, int h, int nb)
 {
-    /* same size as the previous image of this context: planes, descriptors and the device copy of the geometry stand */
-    if (c->have_image && w == c->in_w && h == c->in_h && c->pd.n_oct > 0) return 0;
-    int n_oct, bw, bh;
-    plan_dims(c, w, h, c->frozen_octaves, &n_oct, &bw, &bh);
-    if (bw < 1 || bh < 1) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image is empty");
-    /* candidates pack (x, y) into 16 bits each; the reference's Plane2D uses short dims too (plane_2d.h:257) */
-    if (bw > 32767 || bh > 32767) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image exceeds 32767 pixels per side");
-    if (c->sc.filter_max > 0 && !filter_supported(n_oct, c->sc.max_extrema, c->sc.grid_size))
-        return fail(c, POPSIFT_HIP_ERR_INVALID, "grid filter: grid size > 64 or octaves * max_extrema >= 2^25");
-    c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */
+    const bool same = c->have_image && w == c->in_w && h == c->in_h && c->pd.n_oct > 0;
+    PyrDesc    pd = c->pd;
+    int        bw = c->rep.base_w, bh = c->rep.base_h;
+    size_t     total = 0;
+    if (!same) {
+        int n_oct;
+        plan_dims(c, w, h, c->frozen_octaves, &n_oct, &bw, &bh);
+        if (bw < 1 || bh < 1) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image is empty");
+        /* candidates pack (x, y) into 16 bits each; the reference's Plane2D uses short dims too (plane_2d.h:257) */
+        if (bw > 32767 || bh > 32767) return fail(c, POPSIFT_HIP_ERR_INVALID, "scaled image exceeds 32767 pixels per side");
+        if (c->sc.filter_max > 0 && !filter_supported(n_oct, c->sc.max_extrema, c->sc.grid_size))
+            return fail(c, POPSIFT_HIP_ERR_INVALID, "grid filter: grid size > 64 or octaves * max_extrema >= 2^25");
+        c->frozen_octaves = n_oct; /* popsift.cpp:111: decided by the first image */
 
-    c->in_w = c->in_h = 0;
-    c->have_image = false;
-    c->pd.n_oct = 0;
-
-    PyrDesc pd;
-    memset(&pd, 0, sizeof(pd));
-    pd.n_oct = n_oct;
-    pd.levels = c->levels;
-    pd.L = c->L;
-    /* DoG planes are not stored (params.store_dog = 0): detection and refinement subtract the Gaussian planes they
-     * load -- the same f32 subtraction make_dog does (s_pyramid_build.cu:74-92), so results are bit-identical, with a
-     * third fewer bytes per level launch and an octave-0 working set that fits the last-level cache.  The arena then
-     * holds L planes per octave plus ONE scratch plane (the size of octave 0's) into which the debug download forms a
-     * DoG plane on demand; with store_dog = 1 it holds the reference's 2L-1 planes per octave. */
-    pd.dog_fly = c->p.store_dog ? 0 : 1;
-    size_t total = 0;
-    int    ow = bw, oh = bh, tiles = 0;
-    for (int o = 0; o < n_oct; o++) {
-        OctDesc& od = pd.o[o];
-        od.w = ow;
-        od.h = oh;
-        od.pitch = (ow + PITCH_ALIGN - 1) / PITCH_ALIGN * PITCH_ALIGN;
-        od.plane_stride = (int64_t)od.pitch * oh;
-        od.tile_begin = tiles;
-        tiles += extrema_units(ow, oh);
-        total += (size_t)od.plane_stride * (size_t)(pd.dog_fly ? c->L : 2 * c->L - 1);
-        ow = (int)ceilf(ow / 2.0f); /* sift_pyramid.cu:132-133 */
-        oh = (int)ceilf(oh / 2.0f);
-    }
-    if (pd.dog_fly) total += (size_t)pd.o[0].plane_stride;
-    pd.total_tiles = tiles;
-    if (int rc = grow(c, &c->d_arena, &c->arena_cap, total)) return rc;
-    float* p = c->d_arena;
-    float* scratch = c->d_arena + (total - (size_t)pd.o[0].plane_stride);
-    for (int o = 0; o < n_oct; o++) {
-        OctDesc& od = pd.o[o];
-        od.data = p;
-        od.data_off = p - c->d_arena;
-        p += od.plane_stride * c->L;
-        if (pd.dog_fly) {
-            od.dog = scratch; /* download_plane(kind = 1) only */
-            od.dog_off = scratch - c->d_arena;
-        } else {
-            od.dog = p;
-            od.dog_off = p - c->d_arena;
-            p += od.plane_stride * (c->L - 1);
-        }
-    }
-    const size_t need_ext = (size_t)n_oct * (size_t)c->sc.max_extrema;
-    if (need_ext > c->ext_cap) {
-        /* each buffer keeps its own capacity: a failed grow leaves the others consistent */
+        c->in_w = c->in_h = 0;
+        c->have_image = false;
+        c->pd.n_oct = 0;
         c->ext_cap = 0;
-        if (int rc = grow(c, &c->d_iext, &c->iext_cap, need_ext)) return rc;
-        if (int rc = grow(c, &c->d_ext, &c->extrec_cap, need_ext)) return rc;
-        if (int rc = grow(c, &c->d_feats, &c->feats_cap, need_ext)) return rc;
-        if (c->sc.filter_max > 0)
-            if (int rc = grow(c, &c->d_iext2, &c->iext2_cap, need_ext)) return rc;
-        c->ext_cap = need_ext;
+        for (int k = 0; k < PS_MAX_BATCH; k++) c->slot[k].sized = false;
+
+        memset(&pd, 0, sizeof(pd));
+        pd.n_oct = n_oct;
+        pd.levels = c->levels;
+        pd.L = c->L;
+        /* DoG planes are not stored (params.store_dog = 0): detection and refinement subtract the Gaussian planes they
+         * load -- the same f32 subtraction make_dog does (s_pyramid_build.cu:74-92), so results are bit-identical, with a
+         * third fewer bytes per level launch and an octave-0 working set that fits the last-level cache.  An arena then
+         * holds L planes per octave plus ONE scratch plane (the size of octave 0's) into which the debug download forms a
+         * DoG plane on demand; with store_dog = 1 it holds the reference's 2L-1 planes per octave.  Planes are described
+         * by their float offsets from the arena base, the same for every image of a batch (OctDesc::data_off / dog_off;
+         * the absolute pointers of OctDesc are not used). */
+        pd.dog_fly = c->p.store_dog ? 0 : 1;
+        int ow = bw, oh = bh, tiles = 0;
+        for (int o = 0; o < n_oct; o++) {
+            OctDesc& od = pd.o[o];
+            od.w = ow;
+            od.h = oh;
+            od.pitch = (ow + PITCH_ALIGN - 1) / PITCH_ALIGN * PITCH_ALIGN;
+            od.plane_stride = (int64_t)od.pitch * oh;
+            od.tile_begin = tiles;
+            tiles += extrema_units(ow, oh);
+            od.data_off = (int64_t)total;
+            total += (size_t)od.plane_stride * (size_t)c->L;
+            if (!pd.dog_fly) {
+                od.dog_off = (int64_t)total;
+                total += (size_t)od.plane_stride * (size_t)(c->L - 1);
+            }
+            ow = (int)ceilf(ow / 2.0f); /* sift_pyramid.cu:132-133 */
+            oh = (int)ceilf(oh / 2.0f);
+        }
+        if (pd.dog_fly) {
+            for (int o = 0; o < n_oct; o++) pd.o[o].dog_off = (int64_t)total; /* download_plane(kind = 1) only */
+            total += (size_t)pd.o[0].plane_stride;
+        }
+        pd.total_tiles = tiles;
+    } else {
+        const OctDesc& last = pd.o[pd.n_oct - 1];
+        total = pd.dog_fly ? (size_t)pd.o[0].dog_off + (size_t)pd.o[0].plane_stride
+                           : (size_t)last.dog_off + (size_t)last.plane_stride * (size_t)(c->L - 1);
     }
-    if (int rc = grow(c, &c->d_partial, &c->partial_cap, (need_ext / scan_chunk() + 2) * scan_partials_per_chunk())) return rc;
-    /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
-    if (int rc = ensure_desc_cap(c, std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4)))
-        return rc;
-    if (int rc = ensure_cand_cap(c, std::max(c->cand_cap_init, DET_SUBQ))) return rc;
-    /* orientation histograms: 2 * max_extrema extrema to start with (all octaves together seldom exceed one octave's
-     * cap); finish() grows the buffer and re-runs the keypoint stages when an image has more */
-    if (int rc = ensure_ohist_cap(c, c->ohist_cap_init > 0 ? (size_t)c->ohist_cap_init
-                                                             : std::min(need_ext, (size_t)2 * c->sc.max_extrema)))
-        return rc;
-    if (int rc = grow(c, &c->d_ovf, &c->ovf_cap, (size_t)tiles + 1)) return rc;
-    /* the stream is idle here (submit drains the previous image first), so h_pd is free to reuse */
-    *c->h_pd = pd;
-    HIP_TRY(c, hipMemcpyAsync(c->d_pd, c->h_pd, sizeof(PyrDesc), hipMemcpyHostToDevice, c->stream));
-    c->pd = pd;
-    c->in_w = w;
-    c->in_h = h;
-    c->rep.num_octaves = n_oct;
-    c->rep.base_w = bw;
-    c->rep.base_h = bh;
-    double px = 0;
-    for (int o = 0; o < n_oct; o++) px += (double)pd.o[o].w * pd.o[o].h;
-    c->rep.pyramid_pixels = px;
+    const size_t need_ext = (size_t)pd.n_oct * (size_t)c->sc.max_extrema;
+    for (int k = 0; k < nb; k++) {
+        ImageSlot& s = c->slot[k];
+        if (s.sized) continue;
+        if (int rc = grow(c, &s.d_arena, &s.arena_cap, total)) return rc;
+        /* each buffer keeps its own capacity: a failed grow leaves the others consistent */
+        if (int rc = grow(c, &s.d_iext, &s.iext_cap, need_ext)) return rc;
+        if (int rc = grow(c, &s.d_ext, &s.extrec_cap, need_ext)) return rc;
+        if (int rc = grow(c, &s.d_feats, &s.feats_cap, need_ext)) return rc;
+        if (c->sc.filter_max > 0) {
+            if (int rc = grow(c, &s.d_iext2, &s.iext2_cap, need_ext)) return rc;
+            if (!s.d_fstate) HIP_TRY(c, ctx_malloc(c, (void**)&s.d_fstate, sizeof(FilterState)));
+            if (!s.d_fhist) HIP_TRY(c, ctx_malloc(c, (void**)&s.d_fhist, filter_hist_bytes(c->sc.grid_size)));
+        }
+        if (int rc = grow(c, &s.d_partial, &s.partial_cap, (need_ext / scan_chunk() + 2) * scan_partials_per_chunk())) return rc;
+        /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
+        if (int rc = slot_desc_cap(c, s, std::max(std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4), c->desc_cap)))
+            return rc;
+        if (int rc = slot_cand_cap(c, s, std::max(std::max(c->cand_cap_init, DET_SUBQ), c->cand_cap))) return rc;
+        /* orientation histograms: 2 * max_extrema extrema to start with (all octaves together seldom exceed one octave's
+         * cap); finish() grows the buffer and re-runs the keypoint stages when an image has more */
+        if (int rc = slot_ohist_cap(c, s, std::max(c->ohist_cap_init > 0 ? (size_t)c->ohist_cap_init
+                                                                        : std::min(need_ext, (size_t)2 * c->sc.max_extrema),
+                                                   c->slot[0].sized ? c->ohist_cap : (size_t)0)))
+            return rc;
+        if (int rc = grow(c, &s.d_ovf, &s.ovf_cap, (size_t)pd.total_tiles + 1)) return rc;
+        s.sized = true;
+    }
+    c->ext_cap = need_ext;
+    if (!same) {
+        /* the stream is idle here (submit drains the previous batch first), so h_pd is free to reuse */
+        *c->h_pd = pd;
+        HIP_TRY(c, hipMemcpyAsync(c->d_pd, c->h_pd, sizeof(PyrDesc), hipMemcpyHostToDevice, c->stream));
+        c->pd = pd;
+        c->in_w = w;
+        c->in_h = h;
+        c->rep.num_octaves = pd.n_oct;
+        c->rep.base_w = bw;
+        c->rep.base_h = bh;
+        double px = 0;
+        for (int o = 0; o < pd.n_oct; o++) px += (double)pd.o[o].w * pd.o[o].h;
+        c->rep.pyramid_pixels = px;
+    }
     return 0;
 }
 
@@ -412,16 +490,16 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int t
             c->blur_events.push_back(ep);
         }
         EventPair& ep = c->blur_events[c->blur_events_used++];
-        ep.bytes = alg_bytes;
+        ep.bytes = alg_bytes * c->nb;
         ep.big = (mode == 0 && tile_h == 64);
         /* A level launch is idempotent (reads plane l-1, writes plane l and DoG l-1), so profile mode
          * brackets PROFILE_REPS back-to-back launches with one event pair: the event-to-kernel gap
          * (~4 us, as large as a small launch itself) is amortised instead of being billed per launch. */
         HIP_TRY(c, hipEventRecord(ep.a, c->stream));
-        for (int rep = 0; rep < PROFILE_REPS; rep++) HIP_TRY(c, launch_blur(a, mode, span, tile_h, c->stream));
+        for (int rep = 0; rep < PROFILE_REPS; rep++) HIP_TRY(c, launch_blur(a, c->bd, c->nb, mode, span, tile_h, c->stream));
         HIP_TRY(c, hipEventRecord(ep.b, c->stream));
     } else {
-        HIP_TRY(c, launch_blur(a, mode, span, tile_h, c->stream));
+        HIP_TRY(c, launch_blur(a, c->bd, c->nb, mode, span, tile_h, c->stream));
         SYNC_CHK(c, "k_blur_tile");
     }
     return 0;
@@ -440,25 +518,25 @@ BlurArgs level_args(const popsift_hip_ctx* c, int o, int level)
     a.tiles_x = (od.w + twd - 1) / twd;
     a.tiles_y = (od.h + thd - 1) / thd;
     memcpy(a.taps.g, &c->tab.filter[level * PS_GA], sizeof(a.taps.g));
-    a.dst = od.data + level * od.plane_stride;
-    a.src = od.data + (level - 1) * od.plane_stride;
-    a.dog = pd.dog_fly ? nullptr : od.dog + (level - 1) * od.plane_stride;
-    a.in = nullptr;
+    a.dst_off = od.data_off + level * od.plane_stride;
+    a.src_off = od.data_off + (level - 1) * od.plane_stride;
+    a.dog_off = pd.dog_fly ? -1 : od.dog_off + (level - 1) * od.plane_stride;
     /* level L-3 also writes every second pixel as plane 0 of the next octave (get_by_2_pick_every_second) */
-    a.next0 = (level == pd.L - 3 && o + 1 < pd.n_oct) ? pd.o[o + 1].data : nullptr;
+    a.next0_off = (level == pd.L - 3 && o + 1 < pd.n_oct) ? pd.o[o + 1].data_off : -1;
     a.next_pitch = (o + 1 < pd.n_oct) ? pd.o[o + 1].pitch : 0;
     return a;
 }
 
 /*
- * Pyramid::build_pyramid default branch (s_pyramid_build.cu:549-588), one stream.  Launch order:
+ * Pyramid::build_pyramid default branch (s_pyramid_build.cu:549-588), one stream, every launch for all images of the
+ * batch (gridDim.y).  Launch order:
  *   octave 0: level 0 (from the input image), levels 1 .. L-1;
  *   octave o >= 1: levels 1 .. L-3 (level 0 came with level L-3 of octave o-1); the two last levels of octave o-1
  *   (they feed nothing but detection) ride along with levels 1 and 2 of octave o in ONE launch (k_blur_duo) when both
  *   octaves use 32-row tiles -- 3 instead of 5 dependent launches per small octave;
  *   finally the two last levels of the last octave.
  */
-int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch)
+int enqueue_pyramid(popsift_hip_ctx* c, int is_f32, int pitch, bool aligned4)
 {
     POPSIFT_RANGE("popsift_hip: pyramid");
     const PyrDesc& pd = c->pd;
@@ -480,21 +558,22 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
         a.tiles_x = (od.w + twd - 1) / twd;
         a.tiles_y = (od.h + thd - 1) / thd;
         memcpy(a.taps.g, &c->tab.filter[0], sizeof(a.taps.g));
-        a.dst = od.data;
+        a.dst_off = od.data_off;
+        a.src_off = 0;
+        a.dog_off = -1;
+        a.next0_off = -1;
         float shift = 0.5f;
         if (c->p.sift_mode == POPSIFT_HIP_SIFT_POPSIFT || c->p.sift_mode == POPSIFT_HIP_SIFT_VLFEAT)
             shift = 0.5f * powf(2.0f, c->p.upscale_factor - 0);
-        a.in = d_img;
         a.in_w = c->in_w;
         a.in_h = c->in_h;
         a.in_pitch = pitch;
         a.shift = shift;
         /* weights of the linear upscale are exactly {0, 1/2}: k_blur_tile's copy / average path */
         a.fast2x = (c->p.upscale_factor == 1.0f && shift == 1.0f && od.w == 2 * c->in_w && od.h == 2 * c->in_h) ? 1 : 0;
-        /* ... and a u8 image whose rows all start on 4-byte boundaries: its texels are fetched as aligned dwords */
-        if (a.fast2x && !is_f32 && (pitch & 3) == 0 && ((uintptr_t)d_img & 3) == 0) a.fast2x = 2;
-        a.zero = (int*)c->d_ct; /* this launch clears the image's counters (enqueue_keypoint_stages(c, true)) */
-        a.zero_words = (int)(sizeof(Counters) / sizeof(int));
+        /* ... and u8 images whose rows all start on 4-byte boundaries: the texels are fetched as aligned dwords */
+        if (a.fast2x && !is_f32 && aligned4) a.fast2x = 2;
+        a.zero_words = (int)(sizeof(Counters) / sizeof(int)); /* this launch clears the images' counters (enqueue_keypoint_stages(c, true)) */
         const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * (double)od.w * od.h;
         if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
     }
@@ -508,7 +587,7 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
             const int trail = L - 3 + level; /* L-2, L-1 of the octave before */
             if (pair && level <= 2) {
                 const BlurArgs a = level_args(c, o, level), b = level_args(c, o - 1, trail);
-                HIP_TRY(c, launch_blur_duo(a, c->tab.span[level], b, c->tab.span[trail], c->stream));
+                HIP_TRY(c, launch_blur_duo(a, c->tab.span[level], b, c->tab.span[trail], c->bd, c->nb, c->stream));
                 SYNC_CHK(c, "k_blur_duo");
             } else {
                 if (int rc = single(o, level)) return rc;
@@ -524,90 +603,103 @@ int enqueue_pyramid(popsift_hip_ctx* c, const void* d_img, int is_f32, int pitch
 }
 
 /* Pyramid::step2 + prep_features: extrema -> orientation -> scan -> descriptors -> features */
-InitExt* final_iext(popsift_hip_ctx* c) { return c->sc.filter_max > 0 ? c->d_iext2 : c->d_iext; }
+InitExt* final_iext(popsift_hip_ctx* c, int k = 0) { return c->sc.filter_max > 0 ? c->slot[k].d_iext2 : c->slot[k].d_iext; }
 
-/* counters_cleared: the level-0 launch of this image has zeroed d_ct (submit); re-runs clear it here */
+/* counters_cleared: the level-0 launch of this batch has zeroed the counters (submit); re-runs clear them here */
 int enqueue_keypoint_stages(popsift_hip_ctx* c, bool counters_cleared = false)
 {
     POPSIFT_RANGE("popsift_hip: keypoint stages");
     const bool stages = (c->profile == 2);
+    const bool filtered = c->sc.filter_max > 0;
     auto       mark = [&](int k) -> hipError_t { return stages ? hipEventRecord(c->ev_stage[k], c->stream) : hipSuccess; };
-    if (!counters_cleared) HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters), c->stream));
+    if (!counters_cleared) HIP_TRY(c, hipMemsetAsync(c->d_ct, 0, sizeof(Counters) * (size_t)c->nb, c->stream));
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DETECT)); /* = end of the pyramid stage */
-    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_cand, c->cand_cap, c->d_ovf, c->d_iext,
-                              c->stream, stages ? c->ev_stage[POPSIFT_HIP_STAGE_REFINE] : nullptr));
+    HIP_TRY(c, launch_extrema(c->pd, c->d_pd, c->bd, c->nb, c->sc, c->cand_cap, filtered, c->stream,
+                              stages ? c->ev_stage[POPSIFT_HIP_STAGE_REFINE] : nullptr));
     SYNC_CHK(c, "k_detect / k_refine");
-    if (c->sc.filter_max > 0) {
+    if (filtered) {
         /* Pyramid::orientation's filter hook (s_orientation.cu:353-367); the 10 % test is taken on the device */
-        HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->d_ct, c->d_iext, c->d_iext2, c->d_fstate, c->d_fhist, c->stream));
+        HIP_TRY(c, launch_filter(c->pd.n_oct, c->sc, c->bd, c->nb, c->stream));
         SYNC_CHK(c, "grid filter");
     }
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_ORIENTATION));
-    HIP_TRY(c, launch_orientation(c->d_pd, c->d_arena, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->kp_waves,
-                                  c->stream));
+    HIP_TRY(c, launch_orientation(c->d_pd, c->bd, c->nb, c->sc, filtered, (int)c->ohist_cap, c->kp_waves, c->stream));
     SYNC_CHK(c, "k_orientation");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_SCAN));
     const int n_chunks = (int)(((size_t)c->pd.n_oct * c->sc.max_extrema + scan_chunk() - 1) / scan_chunk());
-    HIP_TRY(c, launch_scan(c->d_pd, c->sc, c->d_ct, final_iext(c), c->d_ohist, (int)c->ohist_cap, c->d_ext, c->d_partial,
-                           std::max(n_chunks, 1), c->d_map, c->d_rot, c->d_drec, c->d_feats, c->desc_cap, c->stream));
+    HIP_TRY(c, launch_scan(c->d_pd, c->bd, c->nb, c->sc, filtered, (int)c->ohist_cap, std::max(n_chunks, 1), c->desc_cap, c->stream));
     SYNC_CHK(c, "k_scan_local / k_scan_apply");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_DESCRIPTOR));
-    HIP_TRY(c, launch_descriptors(c->d_pd, c->d_arena, c->sc, c->d_ct, c->d_ext, c->d_map, c->d_rot, c->d_drec, c->d_desc, c->desc_cap, c->kp_waves,
-                                  c->stream));
+    HIP_TRY(c, launch_descriptors(c->d_pd, c->bd, c->nb, c->sc, c->desc_cap, c->kp_waves, c->stream));
     SYNC_CHK(c, "descriptor kernel");
     HIP_TRY(c, mark(POPSIFT_HIP_STAGE_COUNT));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ct, c->d_ct, sizeof(Counters) * (size_t)c->nb, hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
 
-int submit_common(popsift_hip_ctx* c, const void* img, int on_device, int is_f32, int w, int h, int pitch)
+/* where the images of a batch lie: kind = POPSIFT_HIP_IMG_* */
+int submit_common(popsift_hip_ctx* c, const void* const* imgs, int nb, int kind, int w, int h, int pitch)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
     POPSIFT_RANGE("popsift_hip: submit");
-    if (!img || w <= 0 || h <= 0 || pitch < w) return fail(c, POPSIFT_HIP_ERR_INVALID, "bad image arguments");
+    if (!imgs || nb < 1 || nb > PS_MAX_BATCH || w <= 0 || h <= 0 || pitch < w || kind < 0 || kind > POPSIFT_HIP_IMG_PINNED_F32)
+        return fail(c, POPSIFT_HIP_ERR_INVALID, "bad image arguments");
+    for (int k = 0; k < nb; k++)
+        if (!imgs[k]) return fail(c, POPSIFT_HIP_ERR_INVALID, "bad image arguments");
+    const int is_f32 = kind & 1, where = kind >> 1; /* 0 host, 1 device, 2 pinned host */
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->have_image && !c->finished) {
-        /* one image in flight per context: drain the previous one */
+        /* one batch in flight per context: drain the previous one */
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (int rc = prepare_geometry(c, w, h)) return rc;
+    if (nb > 1 && c->copy_pending) return fail(c, POPSIFT_HIP_ERR_STATE, "a popsift_hip_fetch_begin download is pending");
+    if (int rc = prepare_geometry(c, w, h, nb)) return rc;
+    c->nb = nb;
+    refresh_caps(c);
     const size_t esz = is_f32 ? 4 : 1;
-    const void*  d_img = img;
     int          dpitch = pitch;
-    if (on_device != 1) {
-        size_t cap = c->input_cap;
-        char*  buf = (char*)c->d_input;
+    bool         aligned4 = (pitch & 3) == 0;
+    for (int k = 0; k < nb; k++) {
+        ImageSlot& s = c->slot[k];
+        if (where == 1) {
+            c->bd.s[k].input = imgs[k];
+            aligned4 = aligned4 && ((uintptr_t)imgs[k] & 3) == 0;
+            continue;
+        }
+        size_t cap = s.input_cap;
+        char*  buf = (char*)s.d_input;
         const int rc_in = grow(c, &buf, &cap, (size_t)w * h * esz);
-        c->d_input = buf; /* also after a failed grow, which has freed the old buffer */
-        c->input_cap = cap;
+        s.d_input = buf; /* also after a failed grow, which has freed the old buffer */
+        s.input_cap = cap;
         if (rc_in) return rc_in;
         const size_t bytes = (size_t)w * h * esz;
-        if (on_device == 2) {
+        if (where == 2) {
             /* page-locked memory of the caller, valid until wait(): uploaded from where it lies */
-            HIP_TRY(c, hipMemcpy2DAsync(c->d_input, (size_t)w * esz, img, (size_t)pitch * esz, (size_t)w * esz, (size_t)h,
+            HIP_TRY(c, hipMemcpy2DAsync(s.d_input, (size_t)w * esz, imgs[k], (size_t)pitch * esz, (size_t)w * esz, (size_t)h,
                                         hipMemcpyHostToDevice, c->stream));
         } else {
             /* Like Image::load (s_image.cu:71-79) the caller's buffer is copied into pinned memory before
              * this call returns: the caller may free or reuse it immediately (popsift.cpp:245-247), and an
              * async copy straight from pageable memory would read it later. */
-            if (bytes > c->h_input_cap) {
-                if (c->h_input) HIP_TRY(c, hipHostFree(c->h_input));
-                c->h_input = nullptr;
-                c->h_input_cap = 0;
-                HIP_TRY(c, hipHostMalloc(&c->h_input, bytes, hipHostMallocDefault));
-                c->h_input_cap = bytes;
+            if (bytes > s.h_input_cap) {
+                if (s.h_input) HIP_TRY(c, hipHostFree(s.h_input));
+                s.h_input = nullptr;
+                s.h_input_cap = 0;
+                HIP_TRY(c, hipHostMalloc(&s.h_input, bytes, hipHostMallocDefault));
+                s.h_input_cap = bytes;
             }
             for (int y = 0; y < h; y++)
-                memcpy((char*)c->h_input + (size_t)y * w * esz, (const char*)img + (size_t)y * pitch * esz, (size_t)w * esz);
-            HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_input, bytes, hipMemcpyHostToDevice, c->stream));
+                memcpy((char*)s.h_input + (size_t)y * w * esz, (const char*)imgs[k] + (size_t)y * pitch * esz, (size_t)w * esz);
+            HIP_TRY(c, hipMemcpyAsync(s.d_input, s.h_input, bytes, hipMemcpyHostToDevice, c->stream));
         }
-        d_img = c->d_input;
+        c->bd.s[k].input = s.d_input;
         dpitch = w;
     }
+    if (where != 1) aligned4 = (dpitch & 3) == 0; /* hipMalloc'd buffers are aligned */
     c->blur_events_used = 0;
     HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
     if (c->profile == 2) HIP_TRY(c, hipEventRecord(c->ev_stage[POPSIFT_HIP_STAGE_PYRAMID], c->stream));
-    if (int rc = enqueue_pyramid(c, d_img, is_f32, dpitch)) return rc;
+    if (int rc = enqueue_pyramid(c, is_f32, dpitch, aligned4)) return rc;
     if (int rc = enqueue_keypoint_stages(c, true)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->have_image = true;
@@ -622,49 +714,66 @@ int finish(popsift_hip_ctx* c)
     if (c->finished) return 0;
     POPSIFT_RANGE("popsift_hip: wait");
     HIP_TRY(c, hipSetDevice(c->device));
+    bool rerun = false;
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const bool desc_short = c->h_ct->ori_total > c->desc_cap;
-        int qmax = 0;
-        for (int q = 0; q < DET_SUBQ; q++) qmax = std::max(qmax, c->h_ct->qcnt[q].n);
+        /* the largest need over the images of the batch */
+        int  ori_max = 0, qmax = 0;
+        long ext_max = 0;
+        for (int k = 0; k < c->nb; k++) {
+            const Counters& h = c->h_ct[k];
+            ori_max = std::max(ori_max, h.ori_total);
+            for (int q = 0; q < DET_SUBQ; q++) qmax = std::max(qmax, h.qcnt[q].n);
+            long ext_sum = 0; /* ext_total is written by the scan, which may have run on a clipped list: recount */
+            for (int o = 0; o < c->pd.n_oct; o++) ext_sum += std::min(h.ext_ct[o], c->sc.max_extrema);
+            ext_max = std::max(ext_max, ext_sum);
+        }
+        const bool desc_short = ori_max > c->desc_cap;
         const bool cand_short = qmax > c->cand_cap / DET_SUBQ;
-        long       ext_sum = 0; /* ext_total is written by the scan, which may have run on a clipped list: recount */
-        for (int o = 0; o < c->pd.n_oct; o++) ext_sum += std::min(c->h_ct->ext_ct[o], c->sc.max_extrema);
-        const bool hist_short = (size_t)ext_sum > c->ohist_cap;
+        const bool hist_short = (size_t)ext_max > c->ohist_cap;
         if (!desc_short && !cand_short && !hist_short) break;
         /* more candidates / descriptors than the buffers hold (the reference reallocates between
-         * stages, sift_pyramid.cu:179-209): grow and redo the keypoint stages of this image */
+         * stages, sift_pyramid.cu:179-209): grow and redo the keypoint stages of this batch */
         if (desc_short)
-            if (int rc = ensure_desc_cap(c, c->h_ct->ori_total + c->h_ct->ori_total / 8 + 1024)) return rc;
+            if (int rc = ensure_desc_cap(c, ori_max + ori_max / 8 + 1024)) return rc;
         if (cand_short)
             if (int rc = ensure_cand_cap(c, DET_SUBQ * (qmax + qmax / 8 + 64))) return rc;
         if (hist_short)
-            if (int rc = ensure_ohist_cap(c, (size_t)ext_sum + (size_t)ext_sum / 8 + 1024)) return rc;
+            if (int rc = ensure_ohist_cap(c, (size_t)ext_max + (size_t)ext_max / 8 + 1024)) return rc;
         if (int rc = enqueue_keypoint_stages(c)) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
+        rerun = true;
     }
     popsift_hip_report& r = c->rep;
-    /* per-octave descriptor counts from the octave start offsets the scan left (dct.ori_ps / ori_ct) */
-    int next = c->h_ct->ori_total;
+    for (int k = 0; k < c->nb; k++) {
+        c->n_feat[k] = c->h_ct[k].ext_total;
+        c->n_desc[k] = std::min(c->h_ct[k].ori_total, c->desc_cap);
+    }
+    /* the report describes image 0 of the batch: per-octave descriptor counts from the octave start offsets the scan
+     * left (dct.ori_ps / ori_ct) */
+    Counters& h0 = c->h_ct[0];
+    int       next = h0.ori_total;
     for (int o = PS_MAX_OCT - 1; o >= 0; o--) {
-        if (c->h_ct->ext_ct[o] > 0) {
-            c->h_ct->ori_ct[o] = next - c->h_ct->ori_ps[o];
-            next = c->h_ct->ori_ps[o];
+        if (h0.ext_ct[o] > 0) {
+            h0.ori_ct[o] = next - h0.ori_ps[o];
+            next = h0.ori_ps[o];
         } else {
-            c->h_ct->ori_ct[o] = 0;
-            c->h_ct->ori_ps[o] = next;
+            h0.ori_ct[o] = 0;
+            h0.ori_ps[o] = next;
         }
     }
     for (int o = 0; o < PS_MAX_OCT; o++) {
-        r.ext_ct[o] = c->h_ct->ext_ct[o];
-        r.ori_ct[o] = c->h_ct->ori_ct[o];
+        r.ext_ct[o] = h0.ext_ct[o];
+        r.ori_ct[o] = h0.ori_ct[o];
     }
-    r.ext_total = c->h_ct->ext_total;
-    r.ori_total = std::min(c->h_ct->ori_total, c->desc_cap);
+    r.ext_total = c->n_feat[0];
+    r.ori_total = c->n_desc[0];
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev_begin, c->ev_end) == hipSuccess) r.ms_device = ms;
     for (int k = 0; k < 8; k++) r.ms_stage[k] = 0.0f;
-    if (c->profile == 2)
+    /* after a re-run the stage events of the keypoint stages are the re-run's and the pyramid's event pair spans the
+     * first attempt as well: no stage times then */
+    if (c->profile == 2 && !rerun)
         for (int k = 0; k < POPSIFT_HIP_STAGE_COUNT; k++) {
             float t = 0.0f;
             if (hipEventElapsedTime(&t, c->ev_stage[k], c->ev_stage[k + 1]) == hipSuccess) r.ms_stage[k] = t;
@@ -702,24 +811,27 @@ int drain_copy(popsift_hip_ctx* c)
     return 0;
 }
 
-/* results of the finished image are readable from the current slab (not yet handed to fetch_begin) */
-int results_here(popsift_hip_ctx* c)
+/* results of the finished batch are readable from the current slabs (not yet handed to fetch_begin) */
+int results_here(popsift_hip_ctx* c, int k = 0)
 {
     if (int rc = finish(c)) return rc;
+    if (k < 0 || k >= c->nb) return fail(c, POPSIFT_HIP_ERR_INVALID, "the batch has %d images", c->nb);
     if (c->results_moved)
         return fail(c, POPSIFT_HIP_ERR_STATE, "the results of this image were handed to popsift_hip_fetch_begin");
     return 0;
 }
 
+/* planes of image 0 of the batch (debug / parity hooks) */
 int plane_ptr(popsift_hip_ctx* c, int octave, int kind, int level, float** p, const OctDesc** odp)
 {
     if (!c || !c->have_image) return POPSIFT_HIP_ERR_STATE;
     if (octave < 0 || octave >= c->pd.n_oct || level < 0) return fail(c, POPSIFT_HIP_ERR_INVALID, "bad octave/level");
     const OctDesc& od = c->pd.o[octave];
+    float*         arena = c->slot[0].d_arena;
     if (kind == 0 && level < c->L)
-        *p = od.data + level * od.plane_stride;
+        *p = arena + od.data_off + level * od.plane_stride;
     else if (kind == 1 && level < c->L - 1)
-        *p = c->pd.dog_fly ? od.dog : od.dog + level * od.plane_stride; /* not stored: the scratch plane */
+        *p = arena + od.dog_off + (c->pd.dog_fly ? 0 : level * od.plane_stride); /* not stored: the scratch plane */
     else
         return fail(c, POPSIFT_HIP_ERR_INVALID, "bad plane kind/level");
     *odp = &od;
@@ -870,15 +982,11 @@ int popsift_hip_ctx_create(int device, const popsift_hip_params* p, popsift_hip_
         HIP_TRY(c, hipEventCreate(&c->ev_begin));
         HIP_TRY(c, hipEventCreate(&c->ev_end));
         for (int k = 0; k <= POPSIFT_HIP_STAGE_COUNT; k++) HIP_TRY(c, hipEventCreate(&c->ev_stage[k]));
-        HIP_TRY(c, hipMalloc((void**)&c->d_ct, sizeof(Counters)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_ct, sizeof(Counters) * PS_MAX_BATCH));
         HIP_TRY(c, hipMalloc((void**)&c->d_pd, sizeof(PyrDesc)));
         HIP_TRY(c, hipHostMalloc((void**)&c->h_pd, sizeof(PyrDesc), hipHostMallocDefault));
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_ct, sizeof(Counters), hipHostMallocDefault));
-        memset(c->h_ct, 0, sizeof(Counters));
-        if (p->filter_max_extrema > 0) {
-            HIP_TRY(c, hipMalloc((void**)&c->d_fstate, sizeof(FilterState)));
-            HIP_TRY(c, hipMalloc((void**)&c->d_fhist, filter_hist_bytes(c->sc.grid_size)));
-        }
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_ct, sizeof(Counters) * PS_MAX_BATCH, hipHostMallocDefault));
+        memset(c->h_ct, 0, sizeof(Counters) * PS_MAX_BATCH);
         return 0;
     }();
     if (rc) {
@@ -903,28 +1011,30 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
         if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
-    if (c->d_input) (void)hipFree(c->d_input);
-    if (c->h_input) (void)hipHostFree(c->h_input);
-    if (c->d_arena) (void)hipFree(c->d_arena);
-    if (c->d_iext) (void)hipFree(c->d_iext);
-    if (c->d_iext2) (void)hipFree(c->d_iext2);
-    if (c->d_fstate) (void)hipFree(c->d_fstate);
-    if (c->d_fhist) (void)hipFree(c->d_fhist);
-    if (c->d_ext) (void)hipFree(c->d_ext);
-    if (c->d_ohist) (void)hipFree(c->d_ohist);
-    if (c->d_feats) (void)hipFree(c->d_feats);
-    if (c->d_map) (void)hipFree(c->d_map);
-    if (c->d_rot) (void)hipFree(c->d_rot);
-    if (c->d_drec) (void)hipFree(c->d_drec);
-    if (c->d_desc) (void)hipFree(c->d_desc);
+    for (ImageSlot& sl : c->slot) {
+        if (sl.d_input) (void)hipFree(sl.d_input);
+        if (sl.h_input) (void)hipHostFree(sl.h_input);
+        if (sl.d_arena) (void)hipFree(sl.d_arena);
+        if (sl.d_iext) (void)hipFree(sl.d_iext);
+        if (sl.d_iext2) (void)hipFree(sl.d_iext2);
+        if (sl.d_fstate) (void)hipFree(sl.d_fstate);
+        if (sl.d_fhist) (void)hipFree(sl.d_fhist);
+        if (sl.d_ext) (void)hipFree(sl.d_ext);
+        if (sl.d_ohist) (void)hipFree(sl.d_ohist);
+        if (sl.d_feats) (void)hipFree(sl.d_feats);
+        if (sl.d_map) (void)hipFree(sl.d_map);
+        if (sl.d_rot) (void)hipFree(sl.d_rot);
+        if (sl.d_drec) (void)hipFree(sl.d_drec);
+        if (sl.d_desc) (void)hipFree(sl.d_desc);
+        if (sl.d_cand) (void)hipFree(sl.d_cand);
+        if (sl.d_partial) (void)hipFree(sl.d_partial);
+        if (sl.d_ovf) (void)hipFree(sl.d_ovf);
+    }
     if (c->alt_feats) (void)hipFree(c->alt_feats);
     if (c->alt_desc) (void)hipFree(c->alt_desc);
     if (c->d_ct) (void)hipFree(c->d_ct);
     if (c->d_pd) (void)hipFree(c->d_pd);
     if (c->h_pd) (void)hipHostFree(c->h_pd);
-    if (c->d_cand) (void)hipFree(c->d_cand);
-    if (c->d_partial) (void)hipFree(c->d_partial);
-    if (c->d_ovf) (void)hipFree(c->d_ovf);
     if (c->h_ct) (void)hipHostFree(c->h_ct);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -944,27 +1054,72 @@ int popsift_hip_get_gauss_table(const popsift_hip_ctx* c, float* filter, int* sp
 
 int popsift_hip_submit_u8(popsift_hip_ctx* c, const uint8_t* img, int w, int h, int pitch)
 {
-    return submit_common(c, img, 0, 0, w, h, pitch);
+    const void* one = img;
+    return submit_common(c, &one, 1, POPSIFT_HIP_IMG_HOST_U8, w, h, pitch);
 }
 int popsift_hip_submit_f32(popsift_hip_ctx* c, const float* img, int w, int h, int pitch)
 {
-    return submit_common(c, img, 0, 1, w, h, pitch);
+    const void* one = img;
+    return submit_common(c, &one, 1, POPSIFT_HIP_IMG_HOST_F32, w, h, pitch);
 }
 int popsift_hip_submit_pinned_u8(popsift_hip_ctx* c, const uint8_t* img, int w, int h, int pitch)
 {
-    return submit_common(c, img, 2, 0, w, h, pitch);
+    const void* one = img;
+    return submit_common(c, &one, 1, POPSIFT_HIP_IMG_PINNED_U8, w, h, pitch);
 }
 int popsift_hip_submit_pinned_f32(popsift_hip_ctx* c, const float* img, int w, int h, int pitch)
 {
-    return submit_common(c, img, 2, 1, w, h, pitch);
+    const void* one = img;
+    return submit_common(c, &one, 1, POPSIFT_HIP_IMG_PINNED_F32, w, h, pitch);
 }
 int popsift_hip_submit_dev_u8(popsift_hip_ctx* c, const void* d_img, int w, int h, int pitch)
 {
-    return submit_common(c, d_img, 1, 0, w, h, pitch);
+    return submit_common(c, &d_img, 1, POPSIFT_HIP_IMG_DEV_U8, w, h, pitch);
 }
 int popsift_hip_submit_dev_f32(popsift_hip_ctx* c, const void* d_img, int w, int h, int pitch)
 {
-    return submit_common(c, d_img, 1, 1, w, h, pitch);
+    return submit_common(c, &d_img, 1, POPSIFT_HIP_IMG_DEV_F32, w, h, pitch);
+}
+int popsift_hip_submit_batch(popsift_hip_ctx* c, const void* const* imgs, int n, int kind, int w, int h, int pitch)
+{
+    return submit_common(c, imgs, n, kind, w, h, pitch);
+}
+
+int popsift_hip_wait_batch(popsift_hip_ctx* c, int* n_images, int* n_features, int* n_descriptors)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = finish(c)) return rc;
+    if (n_images) *n_images = c->nb;
+    for (int k = 0; k < c->nb; k++) {
+        if (n_features) n_features[k] = c->n_feat[k];
+        if (n_descriptors) n_descriptors[k] = c->n_desc[k];
+    }
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_fetch_item(popsift_hip_ctx* c, int k, popsift_hip_feature* feats, size_t feats_cap, float* desc, size_t desc_cap)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = results_here(c, k)) return rc;
+    POPSIFT_RANGE("popsift_hip: fetch");
+    const size_t nf = (size_t)c->n_feat[k], nd = (size_t)c->n_desc[k];
+    if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
+    if (feats_cap < nf || desc_cap < nd * 128) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const ImageSlot& sl = c->slot[k];
+    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, sl.d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->stream));
+    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, sl.d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_results_dev_item(popsift_hip_ctx* c, int k, const void** d_feats, const void** d_desc)
+{
+    if (!c) return POPSIFT_HIP_ERR_INVALID;
+    if (int rc = results_here(c, k)) return rc;
+    if (d_feats) *d_feats = c->slot[k].d_feats;
+    if (d_desc) *d_desc = c->slot[k].d_desc;
+    return POPSIFT_HIP_OK;
 }
 
 int popsift_hip_wait(popsift_hip_ctx* c, int* n_features, int* n_descriptors)
@@ -985,8 +1140,8 @@ int popsift_hip_fetch(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t fea
     if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
     if (feats_cap < nf || desc_cap < nd * 128) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, c->d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->stream));
-    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, c->slot[0].d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->stream));
+    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, c->slot[0].d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return POPSIFT_HIP_OK;
 }
@@ -995,6 +1150,7 @@ int popsift_hip_fetch_begin(popsift_hip_ctx* c, popsift_hip_feature* feats, size
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
     if (int rc = results_here(c)) return rc;
+    if (c->nb != 1) return fail(c, POPSIFT_HIP_ERR_STATE, "popsift_hip_fetch_begin serves single-image submits (use popsift_hip_fetch_item)");
     POPSIFT_RANGE("popsift_hip: fetch_begin");
     const size_t nf = (size_t)c->rep.ext_total, nd = (size_t)c->rep.ori_total;
     if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
@@ -1007,20 +1163,22 @@ int popsift_hip_fetch_begin(popsift_hip_ctx* c, popsift_hip_feature* feats, size
      * (four active contexts next to sixteen idle ones: 7.8 -> 6.5 Gpix/s on the sparse workload). */
     if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     /* nothing has been issued or swapped yet: a failed allocation leaves the results where they are (plain fetch works) */
-    if (int rc = grow(c, &c->alt_feats, &c->alt_feats_cap, c->feats_cap)) return rc;
-    if (c->alt_desc_cap < c->desc_cap) {
+    ImageSlot& s0 = c->slot[0];
+    if (int rc = grow(c, &c->alt_feats, &c->alt_feats_cap, s0.feats_cap)) return rc;
+    if (c->alt_desc_cap < s0.desc_cap) {
         if (c->alt_desc) HIP_TRY(c, hipFree(c->alt_desc));
         c->alt_desc = nullptr;
         c->alt_desc_cap = 0;
-        HIP_TRY(c, ctx_malloc(c, (void**)&c->alt_desc, (size_t)c->desc_cap * 128 * sizeof(float)));
-        c->alt_desc_cap = c->desc_cap;
+        HIP_TRY(c, ctx_malloc(c, (void**)&c->alt_desc, (size_t)s0.desc_cap * 128 * sizeof(float)));
+        c->alt_desc_cap = s0.desc_cap;
     }
     /* finish() has synchronised the compute stream: the slab is complete, and copy_stream needs no event to wait on */
-    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, c->d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->copy_stream));
-    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
-    std::swap(c->d_feats, c->alt_feats);
-    std::swap(c->feats_cap, c->alt_feats_cap);
-    std::swap(c->d_desc, c->alt_desc); /* both hold desc_cap descriptors now; d_map / d_rot stay with the context */
+    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, s0.d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->copy_stream));
+    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, s0.d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+    std::swap(s0.d_feats, c->alt_feats);
+    std::swap(s0.feats_cap, c->alt_feats_cap);
+    std::swap(s0.d_desc, c->alt_desc); /* both hold desc_cap descriptors now; d_map / d_rot stay with the slot */
+    refresh_caps(c);
     c->copy_pending = true;
     c->results_moved = true;
     return POPSIFT_HIP_OK;
@@ -1039,8 +1197,8 @@ int popsift_hip_results_dev(popsift_hip_ctx* c, const void** d_feats, const void
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
     if (int rc = results_here(c)) return rc;
-    if (d_feats) *d_feats = c->d_feats;
-    if (d_desc) *d_desc = c->d_desc;
+    if (d_feats) *d_feats = c->slot[0].d_feats;
+    if (d_desc) *d_desc = c->slot[0].d_desc;
     return POPSIFT_HIP_OK;
 }
 
@@ -1063,11 +1221,11 @@ int popsift_hip_clone_results(popsift_hip_ctx* c, popsift_hip_devfeatures** out)
         HIP_TRY(c, hipMalloc((void**)&f->d_desc, sizeof(float) * 128 * (size_t)std::max(f->n_desc, 1)));
         HIP_TRY(c, hipMalloc((void**)&f->d_rev, sizeof(int) * (size_t)std::max(f->n_desc, 1)));
         /* sift_pyramid.cu:323-345: prep_features into the clone, then the two device-to-device copies */
-        HIP_TRY(c, launch_clone_features(c->d_feats, f->n_feat, f->d_desc, f->d_feat, c->stream));
+        HIP_TRY(c, launch_clone_features(c->slot[0].d_feats, f->n_feat, f->d_desc, f->d_feat, c->stream));
         if (f->n_desc > 0) {
-            HIP_TRY(c, hipMemcpyAsync(f->d_desc, c->d_desc, sizeof(float) * 128 * (size_t)f->n_desc,
+            HIP_TRY(c, hipMemcpyAsync(f->d_desc, c->slot[0].d_desc, sizeof(float) * 128 * (size_t)f->n_desc,
                                       hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(f->d_rev, c->d_map, sizeof(int) * (size_t)f->n_desc, hipMemcpyDeviceToDevice,
+            HIP_TRY(c, hipMemcpyAsync(f->d_rev, c->slot[0].d_map, sizeof(int) * (size_t)f->n_desc, hipMemcpyDeviceToDevice,
                                       c->stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1319,8 +1477,8 @@ int popsift_hip_download_plane(popsift_hip_ctx* c, int octave, int kind, int lev
     if (int rc = plane_ptr(c, octave, kind, level, &p, &od)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (kind == 1 && c->pd.dog_fly) /* not stored: DoG(l) = G(l+1) - G(l) into the (otherwise unused) DoG plane */
-        HIP_TRY(c, launch_dog_plane(p, od->data + (level + 1) * od->plane_stride, od->data + level * od->plane_stride,
-                                    (size_t)od->plane_stride, c->stream));
+        HIP_TRY(c, launch_dog_plane(p, c->slot[0].d_arena + od->data_off + (level + 1) * od->plane_stride,
+                                    c->slot[0].d_arena + od->data_off + level * od->plane_stride, (size_t)od->plane_stride, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy2D(out, (size_t)od->w * 4, p, (size_t)od->pitch * 4, (size_t)od->w * 4, od->h,
                            hipMemcpyDeviceToHost));

@@ -327,10 +327,13 @@ constexpr int DET_G = 4;   /* rows per load group (2 and 8, and a double-buffere
 constexpr int DET_Q = 512; /* per-wave candidate queue (entries) */
 
 template <int MODE, int LEVELS, bool SLOW, bool FLY>
-__global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
-                                                SiftConsts sc, Counters* __restrict__ ct, int2* __restrict__ cand,
-                                                int cand_cap, int* __restrict__ ovf)
+__global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp, BatchDesc bd, SiftConsts sc, int cand_cap)
 {
+    /* this image's planes and lists (the slot of blockIdx.y) */
+    const float* __restrict__ arena = bd.s[blockIdx.y].arena;
+    Counters* __restrict__    ct = bd.s[blockIdx.y].ct;
+    int2* __restrict__        cand = bd.s[blockIdx.y].cand;
+    int* __restrict__         ovf = bd.s[blockIdx.y].ovf;
     constexpr int   NP = LEVELS + 2;
     constexpr int   QCAP = SLOW ? ((128 * LEVELS > DET_Q) ? 128 * LEVELS : DET_Q) : DET_Q;
     __shared__ int2 s_queue[4][QCAP];
@@ -499,11 +502,12 @@ __global__ __launch_bounds__(256) void k_detect(const PyrDesc* __restrict__ pdp,
  * gather the four waves first) -- the same hot-counter limit as in the detection kernel.
  */
 template <int MODE, bool FLY>
-__global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, const float* __restrict__ arena,
-                                                SiftConsts sc, Counters* __restrict__ ct,
-                                                const int2* __restrict__ cand, int cand_cap,
-                                                InitExt* __restrict__ iext)
+__global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp, BatchDesc bd, SiftConsts sc, int cand_cap)
 {
+    const float* __restrict__ arena = bd.s[blockIdx.y].arena;
+    Counters* __restrict__    ct = bd.s[blockIdx.y].ct;
+    const int2* __restrict__  cand = bd.s[blockIdx.y].cand;
+    InitExt* __restrict__     iext = bd.s[blockIdx.y].iext;
     __shared__ int s_cnt[PS_MAX_OCT], s_base[PS_MAX_OCT];
     __shared__ int s_pref[DET_SUBQ + 1]; /* 256-candidate steps before each sub-queue */
     const int      lane = threadIdx.x & 63;
@@ -585,19 +589,19 @@ int extrema_units(int w, int h)
 }
 
 template <int MODE>
-static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
-                          Counters* ct, int2* cand, int cand_cap, int* ovf, hipStream_t s)
+static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const BatchDesc& bd, int nb, const SiftConsts& sc,
+                          int cand_cap, hipStream_t s)
 {
-    const dim3 grid((pd.total_tiles + 3) / 4), block(256), sgrid(64);
+    const dim3 grid((pd.total_tiles + 3) / 4, nb), block(256), sgrid(64, nb);
     switch (pd.levels) {
 #define PS_LV(N)                                                                                              \
     case N:                                                                                                   \
         if (pd.dog_fly) {                                                                                     \
-            hipLaunchKernelGGL((k_detect<MODE, N, false, true>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
-            hipLaunchKernelGGL((k_detect<MODE, N, true, true>), sgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+            hipLaunchKernelGGL((k_detect<MODE, N, false, true>), grid, block, 0, s, d_pd, bd, sc, cand_cap);  \
+            hipLaunchKernelGGL((k_detect<MODE, N, true, true>), sgrid, block, 0, s, d_pd, bd, sc, cand_cap);  \
         } else {                                                                                              \
-            hipLaunchKernelGGL((k_detect<MODE, N, false, false>), grid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
-            hipLaunchKernelGGL((k_detect<MODE, N, true, false>), sgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, ovf);  \
+            hipLaunchKernelGGL((k_detect<MODE, N, false, false>), grid, block, 0, s, d_pd, bd, sc, cand_cap);  \
+            hipLaunchKernelGGL((k_detect<MODE, N, true, false>), sgrid, block, 0, s, d_pd, bd, sc, cand_cap);  \
         }                                                                                                     \
         break;
         PS_LV(2) PS_LV(3) PS_LV(4) PS_LV(5) PS_LV(6) PS_LV(7) PS_LV(8) PS_LV(9)
@@ -605,36 +609,39 @@ static void launch_detect(const PyrDesc& pd, const PyrDesc* d_pd, const float* a
     }
 }
 
-hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc,
-                          Counters* ct, int2* cand, int cand_cap, int* ovf, InitExt* iext, hipStream_t s, hipEvent_t mid)
+hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const BatchDesc& bd, int nb, const SiftConsts& sc, int cand_cap,
+                          bool /*filtered*/, hipStream_t s, hipEvent_t mid)
 {
-    if (pd.total_tiles <= 0) return hipSuccess;
+    if (pd.total_tiles <= 0) {
+        if (mid) (void)hipEventRecord(mid, s); /* the stage boundary exists even when there is nothing to detect */
+        return hipSuccess;
+    }
     if (pd.levels < 2 || pd.levels > 9) return hipErrorInvalidValue;
-    const dim3 block(256), rgrid(1024);
+    const dim3 block(256), rgrid(1024, nb);
     switch (sc.sift_mode) {
     case POPSIFT_HIP_SIFT_OPENCV:
-        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
+        launch_detect<POPSIFT_HIP_SIFT_OPENCV>(pd, d_pd, bd, nb, sc, cand_cap, s);
         if (mid) (void)hipEventRecord(mid, s);
         if (pd.dog_fly)
-            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, true>), rgrid, block, 0, s, d_pd, bd, sc, cand_cap);
         else
-            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, false>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_OPENCV, false>), rgrid, block, 0, s, d_pd, bd, sc, cand_cap);
         break;
     case POPSIFT_HIP_SIFT_VLFEAT:
-        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
+        launch_detect<POPSIFT_HIP_SIFT_VLFEAT>(pd, d_pd, bd, nb, sc, cand_cap, s);
         if (mid) (void)hipEventRecord(mid, s);
         if (pd.dog_fly)
-            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, true>), rgrid, block, 0, s, d_pd, bd, sc, cand_cap);
         else
-            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, false>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_VLFEAT, false>), rgrid, block, 0, s, d_pd, bd, sc, cand_cap);
         break;
     default:
-        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, arena, sc, ct, cand, cand_cap, ovf, s);
+        launch_detect<POPSIFT_HIP_SIFT_POPSIFT>(pd, d_pd, bd, nb, sc, cand_cap, s);
         if (mid) (void)hipEventRecord(mid, s);
         if (pd.dog_fly)
-            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, true>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, true>), rgrid, block, 0, s, d_pd, bd, sc, cand_cap);
         else
-            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, false>), rgrid, block, 0, s, d_pd, arena, sc, ct, cand, cand_cap, iext);
+            hipLaunchKernelGGL((k_refine<POPSIFT_HIP_SIFT_POPSIFT, false>), rgrid, block, 0, s, d_pd, bd, sc, cand_cap);
         break;
     }
     return hipGetLastError();

@@ -91,9 +91,11 @@ __device__ __forceinline__ void locator_init(int* s_ps, const Counters* ct, cons
 
 /* per-cell member counts: LDS histogram per workgroup (NC <= FILTER_MAX_CELLS ints), then one global atomic per
  * non-empty cell and workgroup -- with a handful of cells a per-wave atomic would hammer a few hot addresses */
-__global__ __launch_bounds__(256) void k_filter_count(int n_oct, SiftConsts sc, const Counters* __restrict__ ct,
-                                                      const InitExt* __restrict__ iext, FilterState* __restrict__ fs)
+__global__ __launch_bounds__(256) void k_filter_count(int n_oct, SiftConsts sc, BatchDesc bd)
 {
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    const InitExt* __restrict__  iext = bd.s[blockIdx.y].iext;
+    FilterState* __restrict__    fs = bd.s[blockIdx.y].fstate;
     __shared__ int s_ps[PS_MAX_OCT + 1];
     __shared__ int s_hist[FILTER_MAX_CELLS];
     const int      ncell = sc.grid_size * sc.grid_size;
@@ -120,9 +122,10 @@ __global__ __launch_bounds__(256) void k_filter_count(int n_oct, SiftConsts sc, 
 
 /* The host part of extrema_filter_grid (s_filtergrid.cu:204-262) on one workgroup.
  * NC = grid_size^2 <= FILTER_MAX_CELLS counts, sorted ascending by a bitonic network in LDS. */
-__global__ __launch_bounds__(256) void k_filter_limit(int n_oct, SiftConsts sc, const Counters* __restrict__ ct,
-                                                      FilterState* __restrict__ fs)
+__global__ __launch_bounds__(256) void k_filter_limit(int n_oct, SiftConsts sc, BatchDesc bd)
 {
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    FilterState* __restrict__    fs = bd.s[blockIdx.y].fstate;
     __shared__ int s_cnt[FILTER_MAX_CELLS];
     __shared__ int s_scan[2][FILTER_MAX_CELLS];
     __shared__ int s_ct, s_total, s_limit, s_active;
@@ -202,10 +205,12 @@ __global__ __launch_bounds__(256) void k_filter_limit(int n_oct, SiftConsts sc, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_filter_hist(int pass, int n_oct, SiftConsts sc, const Counters* __restrict__ ct,
-                                                     const InitExt* __restrict__ iext,
-                                                     const FilterState* __restrict__ fs, int* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_filter_hist(int pass, int n_oct, SiftConsts sc, BatchDesc bd)
 {
+    const Counters* __restrict__    ct = bd.s[blockIdx.y].ct;
+    const InitExt* __restrict__     iext = bd.s[blockIdx.y].iext;
+    const FilterState* __restrict__ fs = bd.s[blockIdx.y].fstate;
+    int* __restrict__               hist = bd.s[blockIdx.y].fhist;
     __shared__ int s_ps[PS_MAX_OCT + 1];
     locator_init(s_ps, ct, sc, n_oct);
     const int total = s_ps[n_oct];
@@ -235,8 +240,10 @@ __global__ __launch_bounds__(256) void k_filter_hist(int pass, int n_oct, SiftCo
 }
 
 /* one workgroup per cell: walk the 256 digit counts from the top until `remaining` members are covered */
-__global__ __launch_bounds__(256) void k_filter_pick(FilterState* __restrict__ fs, int* __restrict__ hist)
+__global__ __launch_bounds__(256) void k_filter_pick(BatchDesc bd)
 {
+    FilterState* __restrict__ fs = bd.s[blockIdx.y].fstate;
+    int* __restrict__         hist = bd.s[blockIdx.y].fhist;
     __shared__ int s_above[256];
     const int      cell = blockIdx.x, d = threadIdx.x;
     const int      mine = hist[cell * 256 + d];
@@ -260,10 +267,12 @@ __global__ __launch_bounds__(256) void k_filter_pick(FilterState* __restrict__ f
     }
 }
 
-__global__ __launch_bounds__(256) void k_filter_compact(int chunks_per_oct, SiftConsts sc, const Counters* __restrict__ ct,
-                                                        const InitExt* __restrict__ iext, InitExt* __restrict__ out,
-                                                        FilterState* __restrict__ fs, int n_oct)
+__global__ __launch_bounds__(256) void k_filter_compact(int chunks_per_oct, SiftConsts sc, BatchDesc bd, int n_oct)
 {
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    const InitExt* __restrict__  iext = bd.s[blockIdx.y].iext;
+    InitExt* __restrict__        out = bd.s[blockIdx.y].iext2;
+    FilterState* __restrict__    fs = bd.s[blockIdx.y].fstate;
     __shared__ int s_ps[PS_MAX_OCT + 1];
     __shared__ int s_wsum[4];
     __shared__ int s_base;
@@ -308,8 +317,10 @@ __global__ __launch_bounds__(256) void k_filter_compact(int chunks_per_oct, Sift
         if (keep[k]) out[(size_t)o * sc.max_extrema + pos++] = e[k];
 }
 
-__global__ void k_filter_commit(int n_oct, Counters* __restrict__ ct, const FilterState* __restrict__ fs)
+__global__ void k_filter_commit(int n_oct, BatchDesc bd)
 {
+    Counters* __restrict__          ct = bd.s[blockIdx.y].ct;
+    const FilterState* __restrict__ fs = bd.s[blockIdx.y].fstate;
     const int o = threadIdx.x;
     if (o < PS_MAX_OCT) ct->ext_ct[o] = (o < n_oct) ? fs->new_ct[o] : 0;
 }
@@ -324,24 +335,25 @@ bool filter_supported(int n_oct, int max_extrema, int grid_size)
            (long long)n_oct * max_extrema < (1ll << FILTER_IDX_BITS);
 }
 
-hipError_t launch_filter(int n_oct, const SiftConsts& sc, Counters* ct, const InitExt* iext, InitExt* iext_out,
-                         FilterState* fs, int* hist, hipStream_t s)
+hipError_t launch_filter(int n_oct, const SiftConsts& sc, const BatchDesc& bd, int nb, hipStream_t s)
 {
     const int ncell = sc.grid_size * sc.grid_size;
-    hipError_t err = hipMemsetAsync(fs, 0, sizeof(FilterState), s);
-    if (err != hipSuccess) return err;
-    err = hipMemsetAsync(hist, 0, filter_hist_bytes(sc.grid_size), s);
-    if (err != hipSuccess) return err;
+    for (int k = 0; k < nb; k++) {
+        hipError_t err = hipMemsetAsync(bd.s[k].fstate, 0, sizeof(FilterState), s);
+        if (err != hipSuccess) return err;
+        err = hipMemsetAsync(bd.s[k].fhist, 0, filter_hist_bytes(sc.grid_size), s);
+        if (err != hipSuccess) return err;
+    }
     const int sweep = 512; /* grid-stride workgroups of the per-candidate sweeps */
-    hipLaunchKernelGGL(k_filter_count, dim3(64), dim3(256), 0, s, n_oct, sc, ct, iext, fs);
-    hipLaunchKernelGGL(k_filter_limit, dim3(1), dim3(256), 0, s, n_oct, sc, ct, fs);
+    hipLaunchKernelGGL(k_filter_count, dim3(64, nb), dim3(256), 0, s, n_oct, sc, bd);
+    hipLaunchKernelGGL(k_filter_limit, dim3(1, nb), dim3(256), 0, s, n_oct, sc, bd);
     for (int pass = 0; pass < FILTER_PASSES; pass++) {
-        hipLaunchKernelGGL(k_filter_hist, dim3(sweep), dim3(256), 0, s, pass, n_oct, sc, ct, iext, fs, hist);
-        hipLaunchKernelGGL(k_filter_pick, dim3(ncell), dim3(256), 0, s, fs, hist);
+        hipLaunchKernelGGL(k_filter_hist, dim3(sweep, nb), dim3(256), 0, s, pass, n_oct, sc, bd);
+        hipLaunchKernelGGL(k_filter_pick, dim3(ncell, nb), dim3(256), 0, s, bd);
     }
     const int chunks = (sc.max_extrema + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
-    hipLaunchKernelGGL(k_filter_compact, dim3(n_oct * chunks), dim3(256), 0, s, chunks, sc, ct, iext, iext_out, fs, n_oct);
-    hipLaunchKernelGGL(k_filter_commit, dim3(1), dim3(64), 0, s, n_oct, ct, fs);
+    hipLaunchKernelGGL(k_filter_compact, dim3(n_oct * chunks, nb), dim3(256), 0, s, chunks, sc, bd, n_oct);
+    hipLaunchKernelGGL(k_filter_commit, dim3(1, nb), dim3(64), 0, s, n_oct, bd);
     return hipGetLastError();
 }
 

@@ -12,58 +12,57 @@ struct Taps {
     float g[PS_GA];
 };
 
+/* One level launch; the planes are given as float offsets from the arena of the image's slot (sift_types.h, Slot): the
+ * same arguments serve every image of a batch, the kernel adds its slot's arena (blockIdx.y). */
 struct BlurArgs {
-    const float* src; /* plane l-1 (MODE 0)                     */
-    float*       dst; /* plane l                                */
-    float*       dog; /* DoG plane l-1 (MODE 0)                 */
-    int          w, h, pitch;
-    int          tiles_x, tiles_y;
-    const void*  in; /* input image (MODE 1: u8, MODE 2: f32)  */
-    int          in_w, in_h, in_pitch;
-    float        shift;
-    int          fast2x; /* level 0 only: the plane is the input stretched by exactly 2 with source coordinate X / 2 */
-    Taps         taps;
+    int64_t src_off; /* plane l-1 (MODE 0)                     */
+    int64_t dst_off; /* plane l                                */
+    int64_t dog_off; /* DoG plane l-1 (MODE 0), < 0: not stored */
+    int     w, h, pitch;
+    int     tiles_x, tiles_y;
+    /* MODE 1 (u8) / 2 (f32): the input image is Slot::input */
+    int     in_w, in_h, in_pitch;
+    float   shift;
+    int     fast2x; /* level 0 only: the plane is the input stretched by exactly 2 with source coordinate X / 2 (2: u8 rows on 4-byte boundaries) */
+    Taps    taps;
     /* level L-3 only: level 0 of the next octave = every second pixel of this plane (get_by_2_pick_every_second,
-     * s_pyramid_build.cu:50-71), written by the same launch; null otherwise */
-    float*       next0;
-    int          next_pitch;
-    /* level 0 only (the first launch of an image): per-image counters this launch clears, so that the image needs no
-     * separate fill launch before detection; null otherwise */
-    int*         zero;
-    int          zero_words;
+     * s_pyramid_build.cu:50-71), written by the same launch; < 0 otherwise */
+    int64_t next0_off;
+    int     next_pitch;
+    /* level 0 only (the first launch of an image): words of the slot's Counters this launch clears, so that the image needs
+     * no separate fill launch before detection; 0 otherwise */
+    int     zero_words;
 };
 
 int        blur_tile_w();
 int        blur_tile_h(int w, int h); /* 32 or 64 rows, by plane size */
-hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s);
+hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode, int span, int tile_h, hipStream_t s);
 /* two plane-to-plane level launches with 32-row tiles in one (small octaves) */
-hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, hipStream_t s);
+hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, const BatchDesc& bd, int nb, hipStream_t s);
 
 /* extrema.hip */
 hipError_t launch_dog_plane(float* dog, const float* upper, const float* lower, size_t n, hipStream_t s); /* debug / test downloads */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */
+/* Every launcher below takes the slot table `bd` (passed to the kernels by value) and the number of images nb = gridDim.y. */
 /* mid: event recorded between detection and refinement (stage timing), or null */
-hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, int2* cand,
-                          int cand_cap, int* ovf, InitExt* iext, hipStream_t s, hipEvent_t mid);
+hipError_t launch_extrema(const PyrDesc& pd, const PyrDesc* d_pd, const BatchDesc& bd, int nb, const SiftConsts& sc, int cand_cap,
+                          bool filtered, hipStream_t s, hipEvent_t mid);
 
 /* keypoint.hip */
 /* ohist: 36 floats per extremum (the raw orientation histogram), hist_cap extrema */
-hipError_t launch_orientation(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, const InitExt* iext,
-                              float* ohist, int hist_cap, int blocks, hipStream_t s);
+hipError_t launch_orientation(const PyrDesc* d_pd, const BatchDesc& bd, int nb, const SiftConsts& sc, bool filtered, int hist_cap,
+                              int blocks, hipStream_t s);
 int        scan_chunk(); /* extrema per k_scan_apply workgroup */
 int        scan_partials_per_chunk(); /* partial sums k_scan_local leaves per scan_chunk() extrema */
-hipError_t launch_scan(const PyrDesc* d_pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
-                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot, DescRec* drec,
-                       popsift_hip_feature* feats, int desc_cap, hipStream_t s);
-hipError_t launch_descriptors(const PyrDesc* d_pd, const float* arena, const SiftConsts& sc, Counters* ct, const Ext* ext,
-                              const int* map, const float2* rot, const DescRec* drec, float* desc, int desc_cap, int blocks,
+hipError_t launch_scan(const PyrDesc* d_pd, const BatchDesc& bd, int nb, const SiftConsts& sc, bool filtered, int hist_cap,
+                       int n_chunks, int desc_cap, hipStream_t s);
+hipError_t launch_descriptors(const PyrDesc* d_pd, const BatchDesc& bd, int nb, const SiftConsts& sc, int desc_cap, int blocks,
                               hipStream_t s);
 
 /* filter.hip: grid filter between refinement and orientation (s_filtergrid.cu:109-322) */
 bool       filter_supported(int n_oct, int max_extrema, int grid_size);
 size_t     filter_hist_bytes(int grid_size);
-hipError_t launch_filter(int n_oct, const SiftConsts& sc, Counters* ct, const InitExt* iext, InitExt* iext_out,
-                         FilterState* fs, int* hist, hipStream_t s);
+hipError_t launch_filter(int n_oct, const SiftConsts& sc, const BatchDesc& bd, int nb, hipStream_t s);
 
 /* match.hip: brute-force 2-NN (features.cu:157-300) */
 int        match_splits(int l_len, int r_len);

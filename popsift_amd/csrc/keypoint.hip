@@ -294,12 +294,14 @@ constexpr int ORI_COPIES = 4; /* private histogram copies by lane: neighbouring 
  * was ~350 of the kernel's ~1250 vector instructions per extremum, 62 of them dependent cross-lane shuffles).
  * The raw histogram crosses in `ohist` (36 floats per extremum).
  */
-__global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __restrict__ pdp,
-                                                     const float* __restrict__ arena, SiftConsts sc,
-                                                     Counters* __restrict__ ct,
-                                                     const InitExt* __restrict__ iext, float* __restrict__ ohist,
-                                                     int hist_cap)
+__global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __restrict__ pdp, BatchDesc bd, SiftConsts sc,
+                                                     int filtered, int hist_cap)
 {
+    /* this image's planes and lists (the slot of blockIdx.y) */
+    const float* __restrict__   arena = bd.s[blockIdx.y].arena;
+    Counters* __restrict__      ct = bd.s[blockIdx.y].ct;
+    const InitExt* __restrict__ iext = filtered ? bd.s[blockIdx.y].iext2 : bd.s[blockIdx.y].iext;
+    float* __restrict__         ohist = bd.s[blockIdx.y].ohist;
     const int n_oct = pdp->n_oct, L = pdp->L;
     __shared__ fix64 s_hist[KP_NW][ORI_COPIES][PS_ORI_NBINS];
     const int        wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -590,11 +592,14 @@ __device__ __forceinline__ int clamped_total(const Counters* ct, const SiftConst
     return acc;
 }
 
-__global__ __launch_bounds__(SCAN_LT) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                     const Counters* __restrict__ ct, const InitExt* __restrict__ iext,
-                                                     const float* __restrict__ ohist, int hist_cap,
-                                                     Ext* __restrict__ ext, int* __restrict__ partial)
+__global__ __launch_bounds__(SCAN_LT) void k_scan_local(const PyrDesc* __restrict__ pdp, SiftConsts sc, BatchDesc bd,
+                                                     int filtered, int hist_cap)
 {
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    const InitExt* __restrict__  iext = filtered ? bd.s[blockIdx.y].iext2 : bd.s[blockIdx.y].iext;
+    const float* __restrict__    ohist = bd.s[blockIdx.y].ohist;
+    Ext* __restrict__            ext = bd.s[blockIdx.y].ext;
+    int* __restrict__            partial = bd.s[blockIdx.y].partial;
     static_assert(SCAN_CHUNK % SCAN_LCHUNK == 0 && SCAN_LT % 64 == 0, "four lanes per extremum, whole waves");
     __shared__ int s_wsum[SCAN_LT / 64];
     __shared__ int s_ps[PS_MAX_OCT + 1];
@@ -643,12 +648,16 @@ __global__ __launch_bounds__(SCAN_LT) void k_scan_local(const PyrDesc* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc,
-                                                    Counters* __restrict__ ct, Ext* __restrict__ ext,
-                                                    const int* __restrict__ partial, int* __restrict__ map,
-                                                    float2* __restrict__ rot, DescRec* __restrict__ drec,
-                                                    popsift_hip_feature* __restrict__ feats, int desc_cap)
+__global__ __launch_bounds__(256) void k_scan_apply(const PyrDesc* __restrict__ pdp, SiftConsts sc, BatchDesc bd,
+                                                    int with_drec, int desc_cap)
 {
+    Counters* __restrict__            ct = bd.s[blockIdx.y].ct;
+    Ext* __restrict__                 ext = bd.s[blockIdx.y].ext;
+    const int* __restrict__           partial = bd.s[blockIdx.y].partial;
+    int* __restrict__                 map = bd.s[blockIdx.y].map;
+    float2* __restrict__              rot = bd.s[blockIdx.y].rot;
+    DescRec* __restrict__             drec = with_drec ? bd.s[blockIdx.y].drec : nullptr;
+    popsift_hip_feature* __restrict__ feats = bd.s[blockIdx.y].feats;
     __shared__ int s_red[4];
     __shared__ int s_ps[PS_MAX_OCT + 1];
     const int      n_oct = pdp->n_oct;
@@ -778,11 +787,12 @@ constexpr int DESC_MAXROWS = 128; /* patch rows handled by the span path */
 #endif
 constexpr int DESC_GL = 64 / DESC_GROUPS; /* lanes per group */
 
-__global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __restrict__ pdp,
-                                                       const float* __restrict__ arena, SiftConsts sc,
-                                                       Counters* __restrict__ ct, const DescRec* __restrict__ drec,
-                                                       float* __restrict__ desc, int desc_cap)
+__global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, SiftConsts sc, int desc_cap)
 {
+    const float* __restrict__   arena = bd.s[blockIdx.y].arena;
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    const DescRec* __restrict__ drec = bd.s[blockIdx.y].drec;
+    float* __restrict__         desc = bd.s[blockIdx.y].desc;
     __shared__ __attribute__((aligned(16))) fix64 s_hist[KP_NW][DESC_COPIES * DESC_CS];
     /* per patch row of the current pass: flat index of its first sample (low 16 bits) | that index minus the first column
      * of its span relative to xmin (high 16 bits, signed), so that column = flat index - (word >> 16) */
@@ -1091,13 +1101,15 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(const PyrDesc* __r
  * The position arithmetic follows the reference operation by operation (the float -> int
  * truncation of "pt + (round(pt + pix) - pt)" included), so the sampled pixels are the oracle's.
  */
-__global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restrict__ pdp,
-                                                         const float* __restrict__ arena, SiftConsts sc,
-                                                         Counters* __restrict__ ct,
-                                                         const Ext* __restrict__ ext, const int* __restrict__ map,
-                                                         const float2* __restrict__ rot, float* __restrict__ desc,
+__global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restrict__ pdp, BatchDesc bd, SiftConsts sc,
                                                          int desc_cap)
 {
+    const float* __restrict__    arena = bd.s[blockIdx.y].arena;
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    const Ext* __restrict__      ext = bd.s[blockIdx.y].ext;
+    const int* __restrict__      map = bd.s[blockIdx.y].map;
+    const float2* __restrict__   rot = bd.s[blockIdx.y].rot;
+    float* __restrict__          desc = bd.s[blockIdx.y].desc;
     __shared__ float s_feat[4][128];
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float*           feat = s_feat[wave];
@@ -1242,13 +1254,15 @@ __device__ __forceinline__ float tex_linear(const float* pl, int w, int h, int p
  * kernel.
  */
 template <bool ILOOP>
-__global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __restrict__ pdp,
-                                                           const float* __restrict__ arena, SiftConsts sc,
-                                                           Counters* __restrict__ ct,
-                                                           const Ext* __restrict__ ext, const int* __restrict__ map,
-                                                           const float2* __restrict__ rot, float* __restrict__ desc,
+__global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __restrict__ pdp, BatchDesc bd, SiftConsts sc,
                                                            int desc_cap)
 {
+    const float* __restrict__    arena = bd.s[blockIdx.y].arena;
+    const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
+    const Ext* __restrict__      ext = bd.s[blockIdx.y].ext;
+    const int* __restrict__      map = bd.s[blockIdx.y].map;
+    const float2* __restrict__   rot = bd.s[blockIdx.y].rot;
+    float* __restrict__          desc = bd.s[blockIdx.y].desc;
     constexpr int    DCOPY = 2;
     /* notile: 256 points per cell, iloop: up to 1024, each <= 361 * 1: low halves stay below 2^32 */
     constexpr int    FBITS = ILOOP ? 13 : 14;
@@ -1409,42 +1423,41 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
 
 }  // namespace
 
-hipError_t launch_orientation(const PyrDesc* pd, const float* arena, const SiftConsts& sc, Counters* ct,
-                              const InitExt* iext, float* ohist, int hist_cap, int blocks, hipStream_t s)
+hipError_t launch_orientation(const PyrDesc* pd, const BatchDesc& bd, int nb, const SiftConsts& sc, bool filtered, int hist_cap,
+                              int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orientation, dim3(blocks / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, iext, ohist, hist_cap);
+    hipLaunchKernelGGL(k_orientation, dim3(blocks / KP_NW, nb), dim3(64 * KP_NW), 0, s, pd, bd, sc, filtered ? 1 : 0, hist_cap);
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const PyrDesc* pd, const SiftConsts& sc, Counters* ct, const InitExt* iext, const float* ohist,
-                       int hist_cap, Ext* ext, int* partial, int n_chunks, int* map, float2* rot, DescRec* drec,
-                       popsift_hip_feature* feats, int desc_cap, hipStream_t s)
+hipError_t launch_scan(const PyrDesc* pd, const BatchDesc& bd, int nb, const SiftConsts& sc, bool filtered, int hist_cap,
+                       int n_chunks, int desc_cap, hipStream_t s)
 {
     /* n_chunks is the capacity of the lists; a 1080p image fills ~300 chunks */
-    hipLaunchKernelGGL(k_scan_local, dim3(std::min(n_chunks * SCAN_SUB, 512 * SCAN_SUB)), dim3(SCAN_LT), 0, s, pd, sc, ct, iext, ohist, hist_cap, ext, partial);
-    hipLaunchKernelGGL(k_scan_apply, dim3(std::min(n_chunks, 1024)), dim3(256), 0, s, pd, sc, ct, ext, partial, map, rot,
-                       sc.desc_mode == POPSIFT_HIP_DESC_LOOP ? drec : nullptr, feats, desc_cap);
+    hipLaunchKernelGGL(k_scan_local, dim3(std::min(n_chunks * SCAN_SUB, 512 * SCAN_SUB), nb), dim3(SCAN_LT), 0, s, pd, sc, bd,
+                       filtered ? 1 : 0, hist_cap);
+    hipLaunchKernelGGL(k_scan_apply, dim3(std::min(n_chunks, 1024), nb), dim3(256), 0, s, pd, sc, bd,
+                       sc.desc_mode == POPSIFT_HIP_DESC_LOOP ? 1 : 0, desc_cap);
     return hipGetLastError();
 }
 
 int scan_chunk() { return SCAN_CHUNK; }
 int scan_partials_per_chunk() { return SCAN_SUB; }
 
-hipError_t launch_descriptors(const PyrDesc* pd, const float* arena, const SiftConsts& sc, Counters* ct,
-                              const Ext* ext, const int* map, const float2* rot, const DescRec* drec, float* desc, int desc_cap,
-                              int blocks, hipStream_t s)
+hipError_t launch_descriptors(const PyrDesc* pd, const BatchDesc& bd, int nb, const SiftConsts& sc, int desc_cap, int blocks,
+                              hipStream_t s)
 {
     /* IGrid (s_desc_igrid.cu:20-83) evaluates the same 40 x 40 point lattice with the same weights as NoTile,
      * cell by cell (each point up to four times); the two differ only in summation order (6e-7 relative in the
      * oracle), so both run the one-evaluation-per-point kernel */
     if (sc.desc_mode == POPSIFT_HIP_DESC_NOTILE || sc.desc_mode == POPSIFT_HIP_DESC_IGRID)
-        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_notile<false>, dim3(blocks / 4, nb), dim3(256), 0, s, pd, bd, sc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_ILOOP)
-        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_notile<true>, dim3(blocks / 4, nb), dim3(256), 0, s, pd, bd, sc, desc_cap);
     else if (sc.desc_mode == POPSIFT_HIP_DESC_GRID)
-        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks / 4), dim3(256), 0, s, pd, arena, sc, ct, ext, map, rot, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor_grid, dim3(blocks / 4, nb), dim3(256), 0, s, pd, bd, sc, desc_cap);
     else
-        hipLaunchKernelGGL(k_descriptor, dim3(blocks / KP_NW), dim3(64 * KP_NW), 0, s, pd, arena, sc, ct, drec, desc, desc_cap);
+        hipLaunchKernelGGL(k_descriptor, dim3(blocks / KP_NW, nb), dim3(64 * KP_NW), 0, s, bd, sc, desc_cap);
     return hipGetLastError();
 }
 

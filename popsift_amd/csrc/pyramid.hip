@@ -99,8 +99,15 @@ constexpr int blur_lds_floats()
  * all NT / 32 half-waves and each block's four output rows of the vertical pass to LP lanes, so a lane executes about
  * 1 / LP of the instructions (the values and their order per output do not change). */
 template <int HALO, int MODE, int TH, int NT, int LP = 1>
-__device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, float* __restrict__ s_t)
+__device__ __forceinline__ void blur_tile_body(const BlurArgs& a, const BatchDesc& bd, int block, float* __restrict__ s_t)
 {
+    /* this image's planes (the slot of blockIdx.y) */
+    float* const       arena = bd.s[blockIdx.y].arena;
+    const float* const a_src = arena + a.src_off;
+    float* const       a_dst = arena + a.dst_off;
+    float* const       a_dog = a.dog_off >= 0 ? arena + a.dog_off : nullptr;
+    float* const       a_next0 = a.next0_off >= 0 ? arena + a.next0_off : nullptr;
+    const void* const  a_in = bd.s[blockIdx.y].input;
     static_assert(LP == 1 || (MODE == 0 && (LP == 2 || LP == 4)), "LP > 1: plane-to-plane only");
     constexpr int NB = NT / LP;           /* lanes that own a 4x4 block each   */
     constexpr int HP = (HALO + 3) & ~3;   /* left/right halo, padded to 16 B   */
@@ -119,7 +126,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
         constexpr int CH = SW / 4;                 /* chunks per row   */
         constexpr int NCH = SR * CH;               /* chunks per tile  */
         constexpr int NLD = (NCH + NT - 1) / NT;   /* chunks per lane  */
-        const float* __restrict__ src = a.src;
+        const float* __restrict__ src = a_src;
         v4f v[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
@@ -199,7 +206,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
             const int  sx0 = ((tx0 - HP) >> 1) & ~3; /* floor to a multiple of 4 (also for negative values) */
             const int  sy0 = (ty0 - HALO) >> 1;
             const bool inside = sx0 >= 0 && sx0 + RWP <= a.in_w && sy0 >= 0 && sy0 + RHC <= a.in_h;
-            const uint8_t* in8 = (const uint8_t*)a.in;
+            const uint8_t* in8 = (const uint8_t*)a_in;
             auto unit = [](float v) -> float { /* v / 255.0f, correctly rounded, for v = 0 .. 255 */
                 const float r = 0.003921568859368563f; /* RN(1 / 255) */
                 const float q = v * r;
@@ -265,7 +272,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                     const int i = tid + k * NT;
                     if (i < n) {
                         const int r = i / RW, c = i - r * RW;
-                        b[k] = ((const uint8_t*)a.in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
+                        b[k] = ((const uint8_t*)a_in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
                     }
                 }
 #pragma unroll
@@ -280,7 +287,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                     const int i = tid + k * NT;
                     if (i < n) {
                         const int r = i / RW, c = i - r * RW;
-                        b[k] = ((const float*)a.in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
+                        b[k] = ((const float*)a_in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
                     }
                 }
 #pragma unroll
@@ -332,7 +339,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                     const int i = tid + k * NT;
                     if (i < n) {
                         const int r = i / RW, c = i - r * RW;
-                        b[k] = ((const uint8_t*)a.in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
+                        b[k] = ((const uint8_t*)a_in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
                     }
                 }
 #pragma unroll
@@ -347,7 +354,7 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                     const int i = tid + k * NT;
                     if (i < n) {
                         const int r = i / RW, c = i - r * RW;
-                        b[k] = ((const float*)a.in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
+                        b[k] = ((const float*)a_in)[(size_t)(ys0 + r) * a.in_pitch + xs0 + c];
                     }
                 }
 #pragma unroll
@@ -378,16 +385,16 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                 const int   y0 = clampi(iy, 0, a.in_h - 1), y1 = clampi(iy + 1, 0, a.in_h - 1);
                 float       t00, t10, t01, t11;
                 if (MODE == 1) {
-                    const uint8_t* r0 = (const uint8_t*)a.in + (size_t)y0 * a.in_pitch;
-                    const uint8_t* r1 = (const uint8_t*)a.in + (size_t)y1 * a.in_pitch;
+                    const uint8_t* r0 = (const uint8_t*)a_in + (size_t)y0 * a.in_pitch;
+                    const uint8_t* r1 = (const uint8_t*)a_in + (size_t)y1 * a.in_pitch;
                     const int      b00 = r0[x0], b10 = r0[x1], b01 = r1[x0], b11 = r1[x1];
                     t00 = s_lut[b00];
                     t10 = s_lut[b10];
                     t01 = s_lut[b01];
                     t11 = s_lut[b11];
                 } else {
-                    const float* r0 = (const float*)a.in + (size_t)y0 * a.in_pitch;
-                    const float* r1 = (const float*)a.in + (size_t)y1 * a.in_pitch;
+                    const float* r0 = (const float*)a_in + (size_t)y0 * a.in_pitch;
+                    const float* r1 = (const float*)a_in + (size_t)y1 * a.in_pitch;
                     t00 = r0[x0];
                     t10 = r0[x1];
                     t01 = r1[x0];
@@ -491,13 +498,13 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
                     /* the Gaussian plane is the next level's input (keep it cached); the DoG plane is not touched again
                      * before the detection kernel: a non-temporal store keeps it from evicting the plane
                      * (measured: level launches -4 %, detection -7 %; non-temporal for both: levels +20 %) */
-                    *reinterpret_cast<v4f*>(&a.dst[(size_t)gy * pitch + gx]) = acc;
-                    if (LP == 1 && MODE == 0 && a.dog)
-                        __builtin_nontemporal_store(acc - old[g][oo], reinterpret_cast<v4f*>(&a.dog[(size_t)gy * pitch + gx]));
+                    *reinterpret_cast<v4f*>(&a_dst[(size_t)gy * pitch + gx]) = acc;
+                    if (LP == 1 && MODE == 0 && a_dog)
+                        __builtin_nontemporal_store(acc - old[g][oo], reinterpret_cast<v4f*>(&a_dog[(size_t)gy * pitch + gx]));
                     /* the next octave's level 0 takes pixel (2x, 2y): its width is ceil(w / 2), so 2x <= w - 1 always
                      * and the reference's min(2x, w - 1) never clamps.  gx is a multiple of 4. */
-                    if (MODE == 0 && a.next0 && (gy & 1) == 0) {
-                        float* q = a.next0 + (size_t)(gy >> 1) * a.next_pitch + (gx >> 1);
+                    if (MODE == 0 && a_next0 && (gy & 1) == 0) {
+                        float* q = a_next0 + (size_t)(gy >> 1) * a.next_pitch + (gx >> 1);
                         q[0] = acc.x;
                         if (gx + 2 < w) q[1] = acc.z;
                     }
@@ -508,12 +515,14 @@ __device__ __forceinline__ void blur_tile_body(const BlurArgs& a, int block, flo
 }
 
 template <int HALO, int MODE, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
+__global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a, BatchDesc bd)
 {
     __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, TH>()];
-    if (MODE != 0 && a.zero != nullptr && blockIdx.x == gridDim.x - 1)
-        for (int i = threadIdx.x; i < a.zero_words; i += NT) a.zero[i] = 0;
-    blur_tile_body<HALO, MODE, TH, NT>(a, blockIdx.x, s_t);
+    if (MODE != 0 && a.zero_words > 0 && blockIdx.x == gridDim.x - 1) {
+        int* zero = (int*)bd.s[blockIdx.y].ct;
+        for (int i = threadIdx.x; i < a.zero_words; i += NT) zero[i] = 0;
+    }
+    blur_tile_body<HALO, MODE, TH, NT>(a, bd, blockIdx.x, s_t);
 }
 
 /*
@@ -525,40 +534,40 @@ __global__ __launch_bounds__(NT) void k_blur_tile(BlurArgs a)
  * streams, which cost throughput when 16 contexts are in flight).
  */
 template <int HALO, int LP>
-__global__ __launch_bounds__(256 * LP) void k_blur_duo(BlurArgs a, BlurArgs b)
+__global__ __launch_bounds__(256 * LP) void k_blur_duo(BlurArgs a, BlurArgs b, BatchDesc bd)
 {
     __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, 32>()];
     const int na = a.tiles_x * a.tiles_y;
     if ((int)blockIdx.x < na)
-        blur_tile_body<HALO, 0, 32, 256 * LP, LP>(a, blockIdx.x, s_t);
+        blur_tile_body<HALO, 0, 32, 256 * LP, LP>(a, bd, blockIdx.x, s_t);
     else
-        blur_tile_body<HALO, 0, 32, 256 * LP, LP>(b, blockIdx.x - na, s_t);
+        blur_tile_body<HALO, 0, 32, 256 * LP, LP>(b, bd, blockIdx.x - na, s_t);
 }
 
 /* 64-row tiles with LP lanes per 4x4 block (plane-to-plane, DoG not stored) */
 template <int HALO, int NT, int LP>
-__global__ __launch_bounds__(NT) void k_blur_tile64_lp(BlurArgs a)
+__global__ __launch_bounds__(NT) void k_blur_tile64_lp(BlurArgs a, BatchDesc bd)
 {
     __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, 64>()];
-    blur_tile_body<HALO, 0, 64, NT, LP>(a, blockIdx.x, s_t);
+    blur_tile_body<HALO, 0, 64, NT, LP>(a, bd, blockIdx.x, s_t);
 }
 
 /* one small plane, 32-row tiles, LP lanes per block */
 template <int HALO, int LP>
-__global__ __launch_bounds__(256 * LP) void k_blur_small(BlurArgs a)
+__global__ __launch_bounds__(256 * LP) void k_blur_small(BlurArgs a, BatchDesc bd)
 {
     __shared__ __attribute__((aligned(16))) float s_t[blur_lds_floats<HALO, 32>()];
-    blur_tile_body<HALO, 0, 32, 256 * LP, LP>(a, blockIdx.x, s_t);
+    blur_tile_body<HALO, 0, 32, 256 * LP, LP>(a, bd, blockIdx.x, s_t);
 }
 
 /* get_by_2_pick_every_second (s_pyramid_build.cu:50-71) */
 template <int MODE, int TH, int NT>
-hipError_t launch_blur_mode(const BlurArgs& a, int halo, hipStream_t s)
+hipError_t launch_blur_mode(const BlurArgs& a, const BatchDesc& bd, int nb, int halo, hipStream_t s)
 {
-    const dim3 grid(a.tiles_x * a.tiles_y), block(NT);
+    const dim3 grid(a.tiles_x * a.tiles_y, nb), block(NT);
 #define PS_CASE(H)                                                                 \
     if (halo <= H) {                                                               \
-        hipLaunchKernelGGL((k_blur_tile<H, MODE, TH, NT>), grid, block, 0, s, a);  \
+        hipLaunchKernelGGL((k_blur_tile<H, MODE, TH, NT>), grid, block, 0, s, a, bd);  \
         return hipGetLastError();                                                  \
     }
     PS_CASE(4)
@@ -608,18 +617,18 @@ bool blur_is_small(int w, int h) { return (long)((w + TW - 1) / TW) * ((h + 31) 
 
 /* both planes with 32-row tiles and plane-to-plane filtering (mode 0); more lanes per tile when both planes are small
  * and no DoG is stored */
-hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, hipStream_t s)
+hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, const BatchDesc& bd, int nb, hipStream_t s)
 {
     const int halo = std::max(span_a, span_b) - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    const bool small = !a.dog && !b.dog && blur_is_small(a.w, a.h) && blur_is_small(b.w, b.h) && halo <= 16;
-    const dim3 grid(a.tiles_x * a.tiles_y + b.tiles_x * b.tiles_y), block(small ? 256 * BLUR_SMALL_LP : 256);
+    const bool small = a.dog_off < 0 && b.dog_off < 0 && blur_is_small(a.w, a.h) && blur_is_small(b.w, b.h) && halo <= 16;
+    const dim3 grid(a.tiles_x * a.tiles_y + b.tiles_x * b.tiles_y, nb), block(small ? 256 * BLUR_SMALL_LP : 256);
 #define PS_CASE(H)                                                                     \
     if (halo <= H) {                                                                   \
         if (small)                                                                     \
-            hipLaunchKernelGGL((k_blur_duo<H, BLUR_SMALL_LP>), grid, block, 0, s, a, b); \
+            hipLaunchKernelGGL((k_blur_duo<H, BLUR_SMALL_LP>), grid, block, 0, s, a, b, bd); \
         else                                                                           \
-            hipLaunchKernelGGL((k_blur_duo<H, 1>), grid, block, 0, s, a, b);            \
+            hipLaunchKernelGGL((k_blur_duo<H, 1>), grid, block, 0, s, a, b, bd);            \
         return hipGetLastError();                                                      \
     }
     PS_CASE(4)
@@ -633,7 +642,7 @@ hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int
 #undef PS_CASE
 #define PS_CASE(H)                                                        \
     if (halo <= H) {                                                      \
-        hipLaunchKernelGGL((k_blur_duo<H, 1>), grid, block, 0, s, a, b);   \
+        hipLaunchKernelGGL((k_blur_duo<H, 1>), grid, block, 0, s, a, b, bd);   \
         return hipGetLastError();                                         \
     }
     PS_CASE(22)
@@ -643,12 +652,12 @@ hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int
 }
 
 /* one small plane (blur_is_small, 32-row tiles, plane-to-plane, no stored DoG, at most 33 taps) */
-static hipError_t launch_blur_small(const BlurArgs& a, int halo, hipStream_t s)
+static hipError_t launch_blur_small(const BlurArgs& a, const BatchDesc& bd, int nb, int halo, hipStream_t s)
 {
-    const dim3 grid(a.tiles_x * a.tiles_y), block(256 * BLUR_SMALL_LP);
+    const dim3 grid(a.tiles_x * a.tiles_y, nb), block(256 * BLUR_SMALL_LP);
 #define PS_CASE(H)                                                                  \
     if (halo <= H) {                                                                \
-        hipLaunchKernelGGL((k_blur_small<H, BLUR_SMALL_LP>), grid, block, 0, s, a);  \
+        hipLaunchKernelGGL((k_blur_small<H, BLUR_SMALL_LP>), grid, block, 0, s, a, bd);  \
         return hipGetLastError();                                                   \
     }
     PS_CASE(4)
@@ -663,16 +672,16 @@ static hipError_t launch_blur_small(const BlurArgs& a, int halo, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStream_t s)
+hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode, int span, int tile_h, hipStream_t s)
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    if (mode == 0 && tile_h == 32 && !a.dog && halo <= 16 && blur_is_small(a.w, a.h)) return launch_blur_small(a, halo, s);
+    if (mode == 0 && tile_h == 32 && a.dog_off < 0 && halo <= 16 && blur_is_small(a.w, a.h)) return launch_blur_small(a, bd, nb, halo, s);
     /* the 27-tap level of a large plane: 512 lanes, two per 4x4 block -- every lane filters half the rows of the
      * throughput shape and the tile keeps its LDS footprint (24.9 instead of 27.1 us per 3840 x 2160 launch; 1024 lanes
      * with two or four per block: 27.6 / 28.3 us) */
-    if (mode == 0 && tile_h == 64 && !a.dog && halo > 10 && halo <= 13) {
-        hipLaunchKernelGGL((k_blur_tile64_lp<13, 512, 2>), dim3(a.tiles_x * a.tiles_y), dim3(512), 0, s, a);
+    if (mode == 0 && tile_h == 64 && a.dog_off < 0 && halo > 10 && halo <= 13) {
+        hipLaunchKernelGGL((k_blur_tile64_lp<13, 512, 2>), dim3(a.tiles_x * a.tiles_y, nb), dim3(512), 0, s, a, bd);
         return hipGetLastError();
     }
     constexpr int nt64 = 512;
@@ -681,21 +690,21 @@ hipError_t launch_blur(const BlurArgs& a, int mode, int span, int tile_h, hipStr
      * off with 256 lanes */
     if (tile_h == 64 && nt64 == 512 && halo <= 10) {
         switch (mode) {
-        case 0: return launch_blur_mode<0, 64, 512>(a, halo, s);
-        case 1: return launch_blur_mode<1, 64, 512>(a, halo, s);
-        case 2: return launch_blur_mode<2, 64, 512>(a, halo, s);
+        case 0: return launch_blur_mode<0, 64, 512>(a, bd, nb, halo, s);
+        case 1: return launch_blur_mode<1, 64, 512>(a, bd, nb, halo, s);
+        case 2: return launch_blur_mode<2, 64, 512>(a, bd, nb, halo, s);
         }
     } else if (tile_h == 64) {
         switch (mode) {
-        case 0: return launch_blur_mode<0, 64, 256>(a, halo, s);
-        case 1: return launch_blur_mode<1, 64, 256>(a, halo, s);
-        case 2: return launch_blur_mode<2, 64, 256>(a, halo, s);
+        case 0: return launch_blur_mode<0, 64, 256>(a, bd, nb, halo, s);
+        case 1: return launch_blur_mode<1, 64, 256>(a, bd, nb, halo, s);
+        case 2: return launch_blur_mode<2, 64, 256>(a, bd, nb, halo, s);
         }
     } else if (tile_h == 32) {
         switch (mode) {
-        case 0: return launch_blur_mode<0, 32, 256>(a, halo, s);
-        case 1: return launch_blur_mode<1, 32, 256>(a, halo, s);
-        case 2: return launch_blur_mode<2, 32, 256>(a, halo, s);
+        case 0: return launch_blur_mode<0, 32, 256>(a, bd, nb, halo, s);
+        case 1: return launch_blur_mode<1, 32, 256>(a, bd, nb, halo, s);
+        case 2: return launch_blur_mode<2, 32, 256>(a, bd, nb, halo, s);
         }
     }
     return hipErrorInvalidValue;

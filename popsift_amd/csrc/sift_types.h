@@ -8,6 +8,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <hip/hip_vector_types.h> /* int2, float2 */
+
 #include "../../include/popsift_hip.h"
 
 #define PS_MAX_OCT POPSIFT_HIP_MAX_OCTAVES
@@ -105,6 +107,43 @@ struct Counters {
     } qcnt[64];
 };
 #define DET_SUBQ 64
+
+/*
+ * A context extracts up to PS_MAX_BATCH images of one size per submit (round 3: popsift_hip_submit_batch; a plain submit
+ * is a batch of one).  Every image of the batch has a SLOT: its own arena, counters, lists and result slabs -- exactly
+ * what a single-image context owned -- and every kernel of the per-image sequence is launched ONCE for the whole batch
+ * with the image index in blockIdx.y, picking its slot from this table.  The table is a KERNEL ARGUMENT, passed by value
+ * (2 KB of the 4 KB kernarg segment; a wave-uniform index, so the entries come in by scalar loads): pointers read from
+ * the kernarg segment are known to be global, whereas pointers loaded from a table in device memory are generic to the
+ * compiler and every access through them becomes a flat_load / flat_store (tried: 9871 of them in pyramid.hip).
+ * So the 21 latency-bound launches of the small octaves, refinement, the scans and the slow detection pass are paid
+ * once per batch instead of once per image, and the results of an image do not depend on what it is batched with.
+ * Capacities (candidates, histograms, descriptors) are the same for all slots and stay kernel arguments.
+ */
+#define PS_MAX_BATCH POPSIFT_HIP_MAX_BATCH
+struct FilterState;
+struct Slot {
+    float*               arena;
+    Counters*            ct;
+    const void*          input; /* the image (device memory), u8 or f32 */
+    int2*                cand;
+    int*                 ovf;
+    InitExt*             iext;
+    InitExt*             iext2; /* grid filter output (filter enabled only) */
+    FilterState*         fstate;
+    int*                 fhist;
+    float*               ohist;
+    Ext*                 ext;
+    int*                 partial;
+    int*                 map;
+    float2*              rot;
+    DescRec*             drec;
+    popsift_hip_feature* feats;
+    float*               desc;
+};
+struct BatchDesc {
+    Slot s[PS_MAX_BATCH];
+};
 
 /* grid filter working set (filter.hip), device resident */
 #define FILTER_MAX_CELLS 4096 /* grid_size <= 64 */

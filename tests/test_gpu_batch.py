@@ -1,0 +1,89 @@
+"""popsift_hip_submit_batch: several images of one size through every launch together (image index in blockIdx.y).
+Every image has its own slot (planes, lists, result slabs), so its features and descriptors must equal, bit for bit, a
+submit of its own -- whatever it is batched with, in whatever position, also after the buffers had to grow."""
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth
+from util import bits, sorted_features
+
+pytestmark = pytest.mark.gpu
+
+
+def _canon(feats, desc):
+    f, d = sorted_features(feats, desc)
+    return (bits(f["xpos"]), bits(f["ypos"]), bits(f["sigma"]), f["num_ori"].copy(), bits(f["orientation"]), bits(d))
+
+
+def _same(a, b):
+    return all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(sift_mode=1, gauss_mode=3), dict(desc_mode=2), dict(desc_mode=4, norm_mode=1),
+                                dict(filter_max_extrema=600, filter_sorting=1, filter_grid_size=3)],
+                         ids=["default", "opencv", "grid", "notile_classic", "grid_filter"])
+def test_batch_equals_single_submits(gpu_hip, kw):
+    imgs = [synth(400 + k, 320, 240) for k in range(5)]
+    single = gpu_hip.Context(gpu_hip.default_params(**kw))
+    want = [_canon(*single.submit(im).fetch()) for im in imgs]
+    assert len(want[0][0]) > (300 if "filter_max_extrema" in kw else 1000)
+    ctx = gpu_hip.Context(gpu_hip.default_params(**kw))
+    ctx.submit_batch(imgs)
+    counts = ctx.wait_batch()
+    assert len(counts) == 5
+    for k in range(5):
+        assert _same(_canon(*ctx.fetch_item(k)), want[k]), "image %d of the batch differs from its own submit" % k
+    # another order and size of the batch, slots reused; then a single submit on the same context
+    ctx.submit_batch([imgs[3], imgs[0]])
+    assert len(ctx.wait_batch()) == 2
+    assert _same(_canon(*ctx.fetch_item(0)), want[3]) and _same(_canon(*ctx.fetch_item(1)), want[0])
+    assert _same(_canon(*ctx.submit(imgs[4]).fetch()), want[4])
+    assert ctx.wait_batch() == [(len(want[4][0]), len(want[4][5]))]
+    ctx.close()
+    single.close()
+
+
+def test_batch_of_float_images_and_a_change_of_size(gpu_hip):
+    a = [synth(410 + k, 200, 150).astype(np.float32) / 256.0 for k in range(3)]
+    b = [synth(420 + k, 333, 257) for k in range(4)]
+    single = gpu_hip.Context()
+    ctx = gpu_hip.Context()
+    ctx.submit_batch(a)
+    for k, im in enumerate(a):
+        assert _same(_canon(*ctx.fetch_item(k)), _canon(*single.submit(im).fetch()))
+    ctx.submit_batch(b)      # other size (the planes are laid out anew), other dtype, one more slot
+    for k, im in enumerate(b):
+        assert _same(_canon(*ctx.fetch_item(k)), _canon(*gpu_hip.Context().submit(im).fetch()))
+    with pytest.raises(Exception):
+        ctx.submit_batch([a[0], b[0]])
+    ctx.close()
+
+
+def test_batch_regrows_all_slots(gpu_hip):
+    """tiny initial candidate / histogram capacities: the first wait grows the buffers of every slot and re-runs the
+    keypoint stages of the whole batch"""
+    imgs = [synth(430 + k, 400, 300) for k in range(3)]
+    want = [_canon(*gpu_hip.Context().submit(im).fetch()) for im in imgs]
+    ctx = gpu_hip.Context()
+    ctx.debug_set(gpu_hip.DEBUG_CAND_CAP, 256)
+    ctx.debug_set(gpu_hip.DEBUG_OHIST_CAP, 100)
+    ctx.submit_batch(imgs)
+    for k in range(3):
+        assert _same(_canon(*ctx.fetch_item(k)), want[k])
+    ctx.close()
+
+
+def test_batch_argument_errors(gpu_hip):
+    ctx = gpu_hip.Context()
+    im = synth(1, 64, 48)
+    with pytest.raises(Exception):
+        ctx.submit_batch([im] * (gpu_hip.MAX_BATCH + 1))
+    ctx.submit_batch([im, im])
+    with pytest.raises(Exception):
+        ctx.fetch_item(2)
+    with pytest.raises(Exception):
+        ctx.fetch_begin()        # the in-context download overlap serves single-image submits
+    f0, d0 = ctx.fetch_item(0)
+    f1, d1 = ctx.fetch_item(1)
+    assert _same(_canon(f0, d0), _canon(f1, d1))
+    ctx.close()

@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context passes (the command the profiles/ *_single_image* files were taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
+    ap.add_argument("--threshold", type=float, default=None,
+                    help="tuning runs (--quick): Config threshold of the timed loop (0.17: the keypoint-sparse regime)")
     return ap.parse_args()
 
 
@@ -89,9 +91,10 @@ def kernel_counters():
 
 
 class Workers:
-    """One persistent thread per extraction context.  A step hands every context its share of the batch
-    (images i, i + C, i + 2C, ... of the step), which the context extracts back to back; the step ends when
-    every context has finished its last image."""
+    """One persistent thread per extraction context.  run(k) works through k steps -- k batches of len(ptrs) images, one
+    after the other without a pause between them: every context takes the next `launch_batch` images of the stream
+    (submit, wait, next), so no context idles at a step boundary while another finishes its share.  The call returns
+    when the last image of the last step is done."""
 
     def __init__(self, ctxs, ptrs, launch_batch=1):
         self.ctxs, self.ptrs, self.lb = ctxs, ptrs, max(1, launch_batch)
@@ -99,36 +102,53 @@ class Workers:
         self.go = threading.Barrier(self.n + 1)
         self.done = threading.Barrier(self.n + 1)
         self.stop = False
+        self.lock = threading.Lock()
+        self.next = self.end = 0
         self.feats = [0] * self.n
         self.descs = [0] * self.n
         self.threads = [threading.Thread(target=self._loop, args=(i,), daemon=True) for i in range(self.n)]
         for t in self.threads:
             t.start()
 
+    def _take(self):
+        """the next images of the stream: [first, last) or None"""
+        with self.lock:
+            if self.next >= self.end:
+                return None
+            # a launch does not straddle two steps (a step is one batch of the workload)
+            step_end = (self.next // len(self.ptrs) + 1) * len(self.ptrs)
+            a, b = self.next, min(self.next + self.lb, step_end, self.end)
+            self.next = b
+            return a, b
+
     def _loop(self, i):
         ctx = self.ctxs[i]
+        n = len(self.ptrs)
         while True:
             self.go.wait()
             if self.stop:
                 return
             f = d = 0
-            mine = self.ptrs[i::self.n]
-            if self.lb == 1:
-                for p in mine:
-                    ctx.submit_dev(p, W, H, W)
+            while True:
+                t = self._take()
+                if t is None:
+                    break
+                mine = [self.ptrs[k % n] for k in range(*t)]
+                if self.lb == 1:
+                    ctx.submit_dev(mine[0], W, H, W)
                     nf, nd = ctx.wait()
                     f += nf
                     d += nd
-            else:
-                for k in range(0, len(mine), self.lb):
-                    ctx.submit_batch_dev(mine[k:k + self.lb], W, H, W)
+                else:
+                    ctx.submit_batch_dev(mine, W, H, W)
                     for nf, nd in ctx.wait_batch():
                         f += nf
                         d += nd
             self.feats[i], self.descs[i] = f, d
             self.done.wait()
 
-    def step(self):
+    def run(self, steps):
+        self.next, self.end = 0, steps * len(self.ptrs)
         self.go.wait()
         self.done.wait()
 
@@ -226,7 +246,8 @@ def main():
     dev_imgs = [torch.from_numpy(im).cuda(local_rank) for im in host_imgs]  # inputs resident in HBM
     ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
     C = max(1, min(args.contexts, B))
-    ctxs = [hip.Context(hip.default_params(), device=local_rank) for _ in range(C)]
+    pkw = {} if args.threshold is None else {"threshold": args.threshold}
+    ctxs = [hip.Context(hip.default_params(**pkw), device=local_rank) for _ in range(C)]
     workers = Workers(ctxs, ptrs, args.launch_batch)
 
     def barrier():
@@ -237,13 +258,12 @@ def main():
     if args.only_roofline:
         args.steps, args.warmup = 1, 0
     leg("setup")
-    for _ in range(args.warmup):
-        workers.step()
+    if args.warmup:
+        workers.run(args.warmup)
     barrier()
     leg("warmup")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        workers.step()
+    workers.run(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -254,6 +274,7 @@ def main():
     elapsed, (feats_step, descs_step) = reduce_stats(dist if world > 1 else None, elapsed,
                                                      (sum(workers.feats), sum(workers.descs)),
                                                      device="cuda" if backend == "nccl" else "cpu")
+    feats_step, descs_step = feats_step / max(args.steps, 1), descs_step / max(args.steps, 1)   # run() counts all steps
     images = args.steps * B * world
     mpix = images * W * H / 1e6
     value = mpix / elapsed
@@ -350,12 +371,10 @@ def main():
             sp_ctxs = [hip.Context(hip.default_params(threshold=0.17), device=local_rank) for _ in range(4)]
             spw = Workers(sp_ctxs, ptrs)
             n_sp = 8
-            for _ in range(3):   # the single-image legs before this one leave the device idle: let the clocks come back
-                spw.step()
+            spw.run(3)   # the single-image legs before this one leave the device idle: let the clocks come back
             torch.cuda.synchronize()
             t_sp = time.perf_counter()
-            for _ in range(n_sp):
-                spw.step()
+            spw.run(n_sp)
             torch.cuda.synchronize()
             dt_sp = time.perf_counter() - t_sp
             spw.close()

@@ -111,8 +111,11 @@ private:
         std::thread      thread;
         popsift_hip_ctx* ctx = nullptr;
         int              device = 0;
-        void*            pod = nullptr; /* pinned staging for the POD features of a download */
-        size_t           pod_cap = 0;
+        struct Pod { /* pinned staging for the POD features of a download, one per image of a batch */
+            void*  p = nullptr;
+            size_t cap = 0;
+        };
+        std::vector<Pod> pods;
         int              numa_node = -1; /* of the GPU; -1 unknown */
         bool             bind = false;   /* cpus holds the node's CPUs within the process's own affinity mask */
         cpu_set_t        cpus;

@@ -209,6 +209,10 @@ int popsift_hip_wait_batch(popsift_hip_ctx* ctx, int* n_images, int* n_features,
 int popsift_hip_fetch_item(popsift_hip_ctx* ctx, int k, popsift_hip_feature* feats, size_t feats_cap, float* desc,
                            size_t desc_cap);
 int popsift_hip_results_dev_item(popsift_hip_ctx* ctx, int k, const void** d_feats, const void** d_desc);
+/* popsift_hip_fetch_begin (below) for image k of the finished batch: call it for every image whose results are wanted,
+ * submit the next batch, then ONE popsift_hip_fetch_end waits for all the downloads */
+int popsift_hip_fetch_begin_item(popsift_hip_ctx* ctx, int k, popsift_hip_feature* feats, size_t feats_cap, float* desc,
+                                 size_t desc_cap);
 
 /* Replaces the counter read-back of Pyramid::get_descriptors
  * (sift_pyramid.cu:281-294): blocks until the submitted image is finished and

@@ -98,6 +98,7 @@ SYMBOLS = [
     ("popsift_hip_wait_batch", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("popsift_hip_fetch_item", C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("popsift_hip_results_dev_item", C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("popsift_hip_fetch_begin_item", C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("popsift_hip_wait", C.c_int, [_vp, _ip, _ip]),
     ("popsift_hip_fetch", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("popsift_hip_fetch_begin", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
@@ -274,7 +275,11 @@ class PendingFetch:
     def result(self):
         """(feats, desc) as ordinary numpy arrays (copied out of the pinned blocks, which are released)."""
         if not self._done:
-            self._ctx._chk(lib().popsift_hip_fetch_end(self._ctx._h), "popsift_hip_fetch_end")
+            rc = lib().popsift_hip_fetch_end(self._ctx._h)
+            # ERR_STATE: nothing is pending any more -- a later fetch_begin on the context has already waited for this
+            # download (popsift_hip_fetch_begin drains the previous one first, also when it then fails): the data is there
+            if rc != ERR_STATE:
+                self._ctx._chk(rc, "popsift_hip_fetch_end")
             self._landed()
         return self._feats, self._desc
 

@@ -80,6 +80,13 @@ struct ImageSlot {
     int*     d_ovf = nullptr;     /* detection strips handed to the slow pass */
     size_t   ovf_cap = 0;
     bool     sized = false;       /* the buffers fit the context's current geometry */
+    /* second result slab (popsift_hip_fetch_begin_item): the download of this image reads one slab on copy_stream while the
+     * kernels of the next batch write the other.  Invariant: alt caps <= the current slab's; fetch_begin equalises and swaps */
+    popsift_hip_feature* alt_feats = nullptr;
+    size_t   alt_feats_cap = 0;
+    float*   alt_desc = nullptr;
+    int      alt_desc_cap = 0;
+    bool     moved = false; /* the finished image's results went to fetch_begin: the current slab is stale */
 };
 
 struct popsift_hip_ctx {
@@ -111,15 +118,9 @@ struct popsift_hip_ctx {
     /* capacities the kernels are told: the smallest over the slots of the batch (refresh_caps) */
     int       cand_cap = 0, desc_cap = 0;
     size_t    ohist_cap = 0;
-    /* second result slab of slot 0 (popsift_hip_fetch_begin): the download of image i reads one slab on copy_stream while
-     * the kernels of image i+1 write the other.  Invariant: alt caps <= the current slab's; fetch_begin equalises and swaps */
-    popsift_hip_feature* alt_feats = nullptr;
-    size_t   alt_feats_cap = 0;
-    float*   alt_desc = nullptr;
-    int      alt_desc_cap = 0;
     hipStream_t copy_stream = nullptr;
-    bool     copy_pending = false;  /* a fetch_begin download has not been waited for */
-    bool     results_moved = false; /* the finished image's results went to fetch_begin: the current slab is stale */
+    bool     copy_pending = false;  /* fetch_begin downloads have not been waited for */
+    unsigned long submit_seq = 0, copy_seq = 0; /* the batch now in the context / the batch whose downloads are pending */
     Counters* d_ct = nullptr; /* PS_MAX_BATCH counter blocks, one per slot */
     Counters* h_ct = nullptr; /* pinned mirror */
     PyrDesc*  d_pd = nullptr; /* device copy of pd (kernels index octaves dynamically) */
@@ -652,7 +653,6 @@ int submit_common(popsift_hip_ctx* c, const void* const* imgs, int nb, int kind,
         /* one batch in flight per context: drain the previous one */
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (nb > 1 && c->copy_pending) return fail(c, POPSIFT_HIP_ERR_STATE, "a popsift_hip_fetch_begin download is pending");
     if (int rc = prepare_geometry(c, w, h, nb)) return rc;
     c->nb = nb;
     refresh_caps(c);
@@ -704,7 +704,8 @@ int submit_common(popsift_hip_ctx* c, const void* const* imgs, int nb, int kind,
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->have_image = true;
     c->finished = false;
-    c->results_moved = false;
+    c->submit_seq++;
+    for (ImageSlot& sl : c->slot) sl.moved = false;
     return 0;
 }
 
@@ -816,7 +817,7 @@ int results_here(popsift_hip_ctx* c, int k = 0)
 {
     if (int rc = finish(c)) return rc;
     if (k < 0 || k >= c->nb) return fail(c, POPSIFT_HIP_ERR_INVALID, "the batch has %d images", c->nb);
-    if (c->results_moved)
+    if (c->slot[k].moved)
         return fail(c, POPSIFT_HIP_ERR_STATE, "the results of this image were handed to popsift_hip_fetch_begin");
     return 0;
 }
@@ -1029,9 +1030,9 @@ int popsift_hip_ctx_destroy(popsift_hip_ctx* c)
         if (sl.d_cand) (void)hipFree(sl.d_cand);
         if (sl.d_partial) (void)hipFree(sl.d_partial);
         if (sl.d_ovf) (void)hipFree(sl.d_ovf);
+        if (sl.alt_feats) (void)hipFree(sl.alt_feats);
+        if (sl.alt_desc) (void)hipFree(sl.alt_desc);
     }
-    if (c->alt_feats) (void)hipFree(c->alt_feats);
-    if (c->alt_desc) (void)hipFree(c->alt_desc);
     if (c->d_ct) (void)hipFree(c->d_ct);
     if (c->d_pd) (void)hipFree(c->d_pd);
     if (c->h_pd) (void)hipHostFree(c->h_pd);
@@ -1146,42 +1147,49 @@ int popsift_hip_fetch(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t fea
     return POPSIFT_HIP_OK;
 }
 
-int popsift_hip_fetch_begin(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t feats_cap, float* desc, size_t desc_cap)
+int popsift_hip_fetch_begin_item(popsift_hip_ctx* c, int k, popsift_hip_feature* feats, size_t feats_cap, float* desc,
+                                 size_t desc_cap)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
-    if (int rc = results_here(c)) return rc;
-    if (c->nb != 1) return fail(c, POPSIFT_HIP_ERR_STATE, "popsift_hip_fetch_begin serves single-image submits (use popsift_hip_fetch_item)");
+    if (int rc = results_here(c, k)) return rc;
     POPSIFT_RANGE("popsift_hip: fetch_begin");
-    const size_t nf = (size_t)c->rep.ext_total, nd = (size_t)c->rep.ori_total;
+    const size_t nf = (size_t)c->n_feat[k], nd = (size_t)c->n_desc[k];
     if ((nf && !feats) || (nd && !desc)) return fail(c, POPSIFT_HIP_ERR_INVALID, "null output buffer");
     if (feats_cap < nf || desc_cap < nd * 128) return fail(c, POPSIFT_HIP_ERR_TOO_SMALL, "output buffer too small");
     HIP_TRY(c, hipSetDevice(c->device));
-    /* the other slab may still be the source of the previous download */
-    if (int rc = drain_copy(c)) return rc;
+    /* the other slabs may still be the source of the downloads of the batch before this one */
+    if (c->copy_pending && c->copy_seq != c->submit_seq)
+        if (int rc = drain_copy(c)) return rc;
     /* The copy stream is made on first use: the runtime deals its few hardware queues to streams in the order they
      * are created, so a second stream in EVERY context -- used or not -- takes queues from the streams that do the work
      * (four active contexts next to sixteen idle ones: 7.8 -> 6.5 Gpix/s on the sparse workload). */
     if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     /* nothing has been issued or swapped yet: a failed allocation leaves the results where they are (plain fetch works) */
-    ImageSlot& s0 = c->slot[0];
-    if (int rc = grow(c, &c->alt_feats, &c->alt_feats_cap, s0.feats_cap)) return rc;
-    if (c->alt_desc_cap < s0.desc_cap) {
-        if (c->alt_desc) HIP_TRY(c, hipFree(c->alt_desc));
-        c->alt_desc = nullptr;
-        c->alt_desc_cap = 0;
-        HIP_TRY(c, ctx_malloc(c, (void**)&c->alt_desc, (size_t)s0.desc_cap * 128 * sizeof(float)));
-        c->alt_desc_cap = s0.desc_cap;
+    ImageSlot& sl = c->slot[k];
+    if (int rc = grow(c, &sl.alt_feats, &sl.alt_feats_cap, sl.feats_cap)) return rc;
+    if (sl.alt_desc_cap < sl.desc_cap) {
+        if (sl.alt_desc) HIP_TRY(c, hipFree(sl.alt_desc));
+        sl.alt_desc = nullptr;
+        sl.alt_desc_cap = 0;
+        HIP_TRY(c, ctx_malloc(c, (void**)&sl.alt_desc, (size_t)sl.desc_cap * 128 * sizeof(float)));
+        sl.alt_desc_cap = sl.desc_cap;
     }
     /* finish() has synchronised the compute stream: the slab is complete, and copy_stream needs no event to wait on */
-    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, s0.d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->copy_stream));
-    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, s0.d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
-    std::swap(s0.d_feats, c->alt_feats);
-    std::swap(s0.feats_cap, c->alt_feats_cap);
-    std::swap(s0.d_desc, c->alt_desc); /* both hold desc_cap descriptors now; d_map / d_rot stay with the slot */
+    if (nf) HIP_TRY(c, hipMemcpyAsync(feats, sl.d_feats, nf * sizeof(popsift_hip_feature), hipMemcpyDeviceToHost, c->copy_stream));
+    if (nd) HIP_TRY(c, hipMemcpyAsync(desc, sl.d_desc, nd * 128 * sizeof(float), hipMemcpyDeviceToHost, c->copy_stream));
+    std::swap(sl.d_feats, sl.alt_feats);
+    std::swap(sl.feats_cap, sl.alt_feats_cap);
+    std::swap(sl.d_desc, sl.alt_desc); /* both hold desc_cap descriptors now; d_map / d_rot stay with the slot */
     refresh_caps(c);
     c->copy_pending = true;
-    c->results_moved = true;
+    c->copy_seq = c->submit_seq;
+    sl.moved = true;
     return POPSIFT_HIP_OK;
+}
+
+int popsift_hip_fetch_begin(popsift_hip_ctx* c, popsift_hip_feature* feats, size_t feats_cap, float* desc, size_t desc_cap)
+{
+    return popsift_hip_fetch_begin_item(c, 0, feats, feats_cap, desc, desc_cap);
 }
 
 int popsift_hip_fetch_end(popsift_hip_ctx* c)
@@ -1562,7 +1570,7 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* c)
     if (int rc = enqueue_keypoint_stages(c)) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->finished = false;
-    c->results_moved = false;
+    for (ImageSlot& sl : c->slot) sl.moved = false;
     return POPSIFT_HIP_OK;
 }
 

@@ -193,6 +193,14 @@ bool numa_cpu_set(int node, cpu_set_t* out)
     return CPU_COUNT(out) > 0;
 }
 
+/* jobs of one size a worker takes from the queue at once (popsift_hip_submit_batch); it never waits for a batch to fill */
+int jobs_per_submit()
+{
+    const char* e = getenv("POPSIFT_BATCH");
+    const int   k = e ? atoi(e) : 1;
+    return std::min(std::max(k, 1), POPSIFT_HIP_MAX_BATCH);
+}
+
 int contexts_per_device()
 {
     const char* e = getenv("POPSIFT_CONTEXTS_PER_DEVICE");
@@ -340,35 +348,102 @@ void PopSift::worker_loop(Worker* me)
     popsift::setPinnedPoolNode(me->numa_node); /* result blocks this thread takes come from / go to its node's free list */
     /* --log dumps read the context's planes after the image: keep those runs strictly serial */
     const bool overlap = _config.getLogMode() != popsift::Config::All;
-    struct {
+    /* the jobs whose downloads are under way (popsift_hip_fetch_begin_item): completed after the next submit */
+    struct Pending {
         SiftJob*               job = 0;
         popsift::FeaturesHost* features = 0;
         int                    nf = 0;
-    } pending;
-    auto complete_pending = [&]() {
-        if (!pending.job) return;
-        if (popsift_hip_fetch_end(me->ctx) != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
-        convert_features((const popsift_hip_feature*)me->pod, pending.nf, pending.features);
-        pending.job->setFeatures(pending.features);
-        pending.job = 0;
+        int                    pod = 0; /* which staging buffer holds the POD features */
     };
+    std::vector<Pending> pending;
+    auto complete_pending = [&]() {
+        if (pending.empty()) return;
+        if (popsift_hip_fetch_end(me->ctx) != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
+        for (Pending& p : pending) {
+            convert_features((const popsift_hip_feature*)me->pods[(size_t)p.pod].p, p.nf, p.features);
+            p.job->setFeatures(p.features);
+        }
+        pending.clear();
+    };
+    /* pinned staging buffer number k for at least nf POD features (a pageable target would be staged by the runtime at a
+     * fraction of the PCIe rate); the descriptors go directly into the caller-visible pinned block */
+    auto pod_buffer = [&](size_t k, int nf) -> popsift_hip_feature* {
+        if (me->pods.size() <= k) me->pods.resize(k + 1);
+        Worker::Pod& b = me->pods[k];
+        if ((size_t)nf > b.cap) {
+            popsift_hip_host_free(b.p);
+            b.cap = (size_t)nf + (size_t)nf / 4 + 1024;
+            b.p = popsift_hip_host_alloc(b.cap * sizeof(popsift_hip_feature));
+            if (!b.p) DIE("Memory limitation: failed to allocate the feature staging buffer");
+        }
+        return (popsift_hip_feature*)b.p;
+    };
+    const int max_batch = jobs_per_submit();
     for (;;) {
         SiftJob* job = 0;
         bool     quit = false;
+        std::vector<SiftJob*> more; /* further queued jobs of the same size and type, extracted in the same submit */
         {
             std::unique_lock<std::mutex> lk(_mtx);
-            if (!pending.job) _cv.wait(lk, [&] { return !_queue.empty(); });
+            if (pending.empty()) _cv.wait(lk, [&] { return !_queue.empty(); });
             if (!_queue.empty()) {
                 job = _queue.front();
                 if (job == 0)
                     quit = true; /* shutdown marker stays for the other workers */
-                else
+                else {
                     _queue.pop();
+                    while ((int)more.size() + 1 < max_batch && !_queue.empty() && _queue.front() != 0 &&
+                           _queue.front()->getWidth() == job->getWidth() && _queue.front()->getHeight() == job->getHeight() &&
+                           _queue.front()->isFloat() == job->isFloat() && _proc_mode != popsift::Config::MatchingMode &&
+                           _config.getLogMode() != popsift::Config::All) {
+                        more.push_back(_queue.front());
+                        _queue.pop();
+                    }
+                }
             }
         }
         if (quit || !job) {
             complete_pending();
             if (quit) return;
+            continue;
+        }
+        if (!more.empty()) {
+            /* several jobs in one submit: every kernel is launched once for all of them (popsift_hip.h); their downloads
+             * are started together and run under the next submit, like a single job's */
+            POPSIFT_RANGE("PopSift jobs (submit_batch, wait, fetch)");
+            std::vector<SiftJob*> jobs;
+            jobs.push_back(job);
+            jobs.insert(jobs.end(), more.begin(), more.end());
+            bool pinned = true;
+            for (SiftJob* j : jobs) pinned = pinned && j->isPinned();
+            const void* imgs[POPSIFT_HIP_MAX_BATCH];
+            for (size_t k = 0; k < jobs.size(); k++) imgs[k] = jobs[k]->getImageData();
+            const int kind = job->isFloat() ? (pinned ? POPSIFT_HIP_IMG_PINNED_F32 : POPSIFT_HIP_IMG_HOST_F32)
+                                            : (pinned ? POPSIFT_HIP_IMG_PINNED_U8 : POPSIFT_HIP_IMG_HOST_U8);
+            int rc = popsift_hip_submit_batch(me->ctx, imgs, (int)jobs.size(), kind, job->getWidth(), job->getHeight(), job->getWidth());
+            if (rc != POPSIFT_HIP_OK) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
+            complete_pending(); /* the previous jobs' downloads and conversion, under this batch's kernels */
+            int n = 0, nfs[POPSIFT_HIP_MAX_BATCH], nds[POPSIFT_HIP_MAX_BATCH];
+            rc = popsift_hip_wait_batch(me->ctx, &n, nfs, nds);
+            if (rc != POPSIFT_HIP_OK || n != (int)jobs.size()) DIE(string("extraction failed: ") + popsift_hip_last_error(me->ctx));
+            for (int k = 0; k < n; k++) {
+                popsift::FeaturesHost* features = new popsift::FeaturesHost(nfs[k], nds[k]);
+                if (nds[k] == 0) cerr << "Warning: no descriptors extracted" << endl; /* sift_desc.cu:88-92 */
+                if (nfs[k] == 0) {
+                    jobs[(size_t)k]->setFeatures(features);
+                    continue;
+                }
+                popsift_hip_feature* pod = pod_buffer((size_t)k, nfs[k]);
+                rc = popsift_hip_fetch_begin_item(me->ctx, k, pod, me->pods[(size_t)k].cap, (float*)features->getDescriptors(),
+                                                  (size_t)nds[k] * 128);
+                if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
+                Pending p;
+                p.job = jobs[(size_t)k];
+                p.features = features;
+                p.nf = nfs[k];
+                p.pod = k;
+                pending.push_back(p);
+            }
             continue;
         }
         POPSIFT_RANGE("PopSift job (submit, wait, fetch)");
@@ -398,24 +473,19 @@ void PopSift::worker_loop(Worker* me)
         popsift::FeaturesHost* features = new popsift::FeaturesHost(nf, nd);
         if (nd == 0) cerr << "Warning: no descriptors extracted" << endl; /* sift_desc.cu:88-92 */
         if (nf > 0) {
-            /* the POD features land in a pinned buffer of this worker (a pageable target would be staged by the
-             * runtime at a fraction of the PCIe rate), the descriptors directly in the caller-visible pinned block */
-            if ((size_t)nf > me->pod_cap) {
-                popsift_hip_host_free(me->pod);
-                me->pod_cap = (size_t)nf + (size_t)nf / 4 + 1024;
-                me->pod = popsift_hip_host_alloc(me->pod_cap * sizeof(popsift_hip_feature));
-                if (!me->pod) DIE("Memory limitation: failed to allocate the feature staging buffer");
-            }
-            popsift_hip_feature* pod = (popsift_hip_feature*)me->pod;
+            popsift_hip_feature* pod = pod_buffer(0, nf);
             if (overlap) {
-                rc = popsift_hip_fetch_begin(me->ctx, pod, me->pod_cap, (float*)features->getDescriptors(), (size_t)nd * 128);
+                rc = popsift_hip_fetch_begin(me->ctx, pod, me->pods[0].cap, (float*)features->getDescriptors(), (size_t)nd * 128);
                 if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
-                pending.job = job;
-                pending.features = features;
-                pending.nf = nf;
+                Pending p;
+                p.job = job;
+                p.features = features;
+                p.nf = nf;
+                p.pod = 0;
+                pending.push_back(p);
                 continue;
             }
-            rc = popsift_hip_fetch(me->ctx, pod, me->pod_cap, (float*)features->getDescriptors(), (size_t)nd * 128);
+            rc = popsift_hip_fetch(me->ctx, pod, me->pods[0].cap, (float*)features->getDescriptors(), (size_t)nd * 128);
             if (rc != POPSIFT_HIP_OK) DIE(string("download failed: ") + popsift_hip_last_error(me->ctx));
             convert_features(pod, nf, features);
         }
@@ -443,7 +513,7 @@ void PopSift::uninit()
     for (Worker* wk : _workers) {
         if (wk->thread.joinable()) wk->thread.join();
         popsift_hip_ctx_destroy(wk->ctx);
-        popsift_hip_host_free(wk->pod);
+        for (Worker::Pod& b : wk->pods) popsift_hip_host_free(b.p);
         delete wk;
     }
     const bool had_workers = !_workers.empty();

@@ -81,9 +81,15 @@ def test_batch_argument_errors(gpu_hip):
     ctx.submit_batch([im, im])
     with pytest.raises(Exception):
         ctx.fetch_item(2)
-    with pytest.raises(Exception):
-        ctx.fetch_begin()        # the in-context download overlap serves single-image submits
     f0, d0 = ctx.fetch_item(0)
     f1, d1 = ctx.fetch_item(1)
     assert _same(_canon(f0, d0), _canon(f1, d1))
+    # image 0 handed to the overlapped download (popsift_hip_fetch_begin = item 0): gone from the slab, image 1 is not
+    pend = ctx.fetch_begin()
+    with pytest.raises(Exception):
+        ctx.fetch_item(0)
+    assert _same(_canon(*ctx.fetch_item(1)), _canon(f1, d1))
+    ctx.submit_batch([im, im, im])        # the next batch runs under the download
+    assert _same(_canon(*pend.result()), _canon(f0, d0))
+    assert _same(_canon(*ctx.fetch_item(2)), _canon(f0, d0))
     ctx.close()

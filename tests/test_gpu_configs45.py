@@ -159,6 +159,22 @@ def test_eight_gpu_worker_count_on_one_card(tmp_path, gpu_hip):
         assert (nf, nd, dg) == want[i % 16], "job %d (image %d) differs from the single-context run" % (i, i % 16)
 
 
+@pytest.mark.gpu
+def test_worker_takes_several_queued_jobs_per_submit(tmp_path, gpu_hip):
+    """POPSIFT_BATCH=4: a worker takes up to four queued jobs of one size into ONE popsift_hip_submit_batch.  Two image
+    sizes interleaved in runs of different length, 2 workers: every job's digest equals its own single-context run."""
+    _build()
+    imgs = []
+    for k in range(26):
+        imgs.append(synth(500 + k, 480, 360) if (k // 5) % 2 == 0 else synth(500 + k, 333, 257))
+    rows = _run_batch(tmp_path, imgs, env={"POPSIFT_BATCH": "4", "POPSIFT_CONTEXTS_PER_DEVICE": "2", "POPSIFT_DEVICES": "0"})
+    ctx = gpu_hip.Context()
+    for (i, nf, nd, dg), im in zip(rows, imgs):
+        feats, desc = ctx.submit(im).fetch()
+        assert (nf, nd) == (len(feats), len(desc)), i
+        assert dg == digest(feats, desc), "job %d differs from the single-context run" % i
+
+
 MATCH_SRC = r"""
 #include <popsift/features.h>
 #include <popsift/popsift.h>

@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--only-roofline", action="store_true",
                     help="run only the single-context passes (the command the profiles/ *_single_image* files were taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
+    ap.add_argument("--debug", default="", help="tuning runs: popsift_hip_debug_set switches, what:value,...")
     ap.add_argument("--threshold", type=float, default=None,
                     help="tuning runs (--quick): Config threshold of the timed loop (0.17: the keypoint-sparse regime)")
     return ap.parse_args()
@@ -248,6 +249,11 @@ def main():
     C = max(1, min(args.contexts, B))
     pkw = {} if args.threshold is None else {"threshold": args.threshold}
     ctxs = [hip.Context(hip.default_params(**pkw), device=local_rank) for _ in range(C)]
+    if args.debug:      # tuning runs (tools/): popsift_hip_debug_set switches "what:value,..."
+        for item in args.debug.split(","):
+            what, value = item.split(":")
+            for c in ctxs:
+                c.debug_set(int(what), int(value))
     workers = Workers(ctxs, ptrs, args.launch_batch)
 
     def barrier():

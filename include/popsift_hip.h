@@ -305,9 +305,11 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
  * (small values exercise the grow-and-rerun path of popsift_hip_wait); FAIL_ALLOC = n: the n-th device allocation
  * of this context from now on fails with POPSIFT_HIP_ERR_OOM (0 = off); DESC_ROWS = patch rows the loop descriptor
  * walks per pass (4 .. 128, default 128: small values make ordinary patches take the several passes that otherwise only
- * patches of more than 128 rows take -- sigma0 near 2 at the coarsest level; results do not depend on it). */
+ * patches of more than 128 rows take -- sigma0 near 2 at the coarsest level; results do not depend on it); PYR_ORDER = 0:
+ * level 1 of octave 1 after ALL levels of octave 0 (the default), 1: right behind the level that writes its source
+ * plane (results do not depend on it; tools/pyr_order.sh times both). */
 enum { POPSIFT_HIP_DEBUG_DET_QCAP = 1, POPSIFT_HIP_DEBUG_CAND_CAP = 2, POPSIFT_HIP_DEBUG_OHIST_CAP = 3,
-       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5 };
+       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5, POPSIFT_HIP_DEBUG_PYR_ORDER = 6 };
 int popsift_hip_debug_set(popsift_hip_ctx* ctx, int what, int value);
 
 #ifdef __cplusplus

@@ -112,7 +112,9 @@ struct popsift_hip_ctx {
     int       kp_waves = 65536; /* launch size of the keypoint kernels in waves (8 per wave slot of the device) */
     int       det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
     int       desc_rows = 1 << 30;
+    int       pyr_order = 0;
     int       cand_cap_init = 1 << 20;
+    bool      cand_cap_user = false;
     int       ohist_cap_init = 0;
     size_t    ext_cap = 0; /* entries every one of d_iext/d_ext/d_feats(/d_iext2) of the sized slots holds */
     /* capacities the kernels are told: the smallest over the slots of the batch (refresh_caps) */
@@ -453,7 +455,15 @@ int prepare_geometry(popsift_hip_ctx* c, int w, int h, int nb)
         /* sift_pyramid.cu:149: max(2*max_extrema, max_orientations) descriptors to start with */
         if (int rc = slot_desc_cap(c, s, std::max(std::max(2 * c->sc.max_extrema, c->sc.max_extrema + c->sc.max_extrema / 4), c->desc_cap)))
             return rc;
-        if (int rc = slot_cand_cap(c, s, std::max(std::max(c->cand_cap_init, DET_SUBQ), c->cand_cap))) return rc;
+        /* candidates: 64 region slices of one buffer (extrema.hip); a default-sized buffer grows with the pyramid, so that
+         * the first image of a 4K stream does not overflow a slice and re-run (a test's explicit CAND_CAP is taken as is) */
+        int cand0 = std::max(c->cand_cap_init, DET_SUBQ);
+        if (!c->cand_cap_user) {
+            double px = 0;
+            for (int o = 0; o < pd.n_oct; o++) px += (double)pd.o[o].w * pd.o[o].h;
+            cand0 = std::max(cand0, (int)std::min(px / 8.0, 64.0 * 1024 * 1024));
+        }
+        if (int rc = slot_cand_cap(c, s, std::max(cand0, c->cand_cap))) return rc;
         /* orientation histograms: 2 * max_extrema extrema to start with (all octaves together seldom exceed one octave's
          * cap); finish() grows the buffer and re-runs the keypoint stages when an image has more */
         if (int rc = slot_ohist_cap(c, s, std::max(c->ohist_cap_init > 0 ? (size_t)c->ohist_cap_init
@@ -578,13 +588,21 @@ int enqueue_pyramid(popsift_hip_ctx* c, int is_f32, int pitch, bool aligned4)
         const double bytes = (double)c->in_w * c->in_h * (is_f32 ? 4 : 1) + 4.0 * (double)od.w * od.h;
         if (int rc = blur_launch(c, a, is_f32 ? 2 : 1, c->tab.span[0], thd, bytes)) return rc;
     }
-    for (int level = 1; level < L; level++)
+    /* Level 1 of octave 1 reads what level L-3 of octave 0 has just written (every second pixel, 1/4 of a plane): launched
+     * right behind it, that plane still sits in the L2s; after levels L-2 and L-1 of octave 0 (2 x 66 MB through the
+     * caches) it came from HBM, and the launch took 14 us instead of 8 (round 2's "octave-1 anomaly"). */
+    const bool early1 = c->pyr_order == 1 && pd.n_oct >= 2 && L - 3 >= 1;
+    for (int level = 1; level < L; level++) {
         if (int rc = single(0, level)) return rc;
+        if (early1 && level == L - 3)
+            if (int rc = single(1, 1)) return rc;
+    }
     for (int o = 1; o < pd.n_oct; o++) {
         /* per-launch profiling keeps one kernel per event pair */
         const bool pair = c->profile != 1 && o >= 2 && blur_tile_h(pd.o[o].w, pd.o[o].h) == 32 &&
                           blur_tile_h(pd.o[o - 1].w, pd.o[o - 1].h) == 32;
         for (int level = 1; level <= L - 3; level++) {
+            if (early1 && o == 1 && level == 1) continue; /* launched behind level L-3 of octave 0 */
             const int trail = L - 3 + level; /* L-2, L-1 of the octave before */
             if (pair && level <= 2) {
                 const BlurArgs a = level_args(c, o, level), b = level_args(c, o - 1, trail);
@@ -1545,12 +1563,16 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_CAND_CAP:
         c->cand_cap_init = std::max(value, DET_SUBQ);
+        c->cand_cap_user = true;
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_OHIST_CAP:
         c->ohist_cap_init = std::max(value, 1);
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_FAIL_ALLOC:
         c->fail_alloc_in = std::max(value, 0);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_PYR_ORDER:
+        c->pyr_order = value;
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_DESC_ROWS:
         c->desc_rows = c->sc.desc_rows = std::max(value, 4);

@@ -369,3 +369,19 @@ def test_descriptor_passes_do_not_change_the_result(gpu_hip):
     for f, d in res[1:]:
         assert np.array_equal(bits(f["xpos"]), bits(res[0][0]["xpos"]))
         assert np.array_equal(bits(d), bits(res[0][1]))
+
+
+def test_all_texture_in_one_corner(oracle_mod, gpu_hip):
+    """Detection appends to 64 sub-queues, one per image REGION, each with a fixed slice of the candidate buffer: an
+    image whose texture sits in one corner sends (nearly) all its candidates to one slice.  With a buffer of 1024
+    entries (16 per slice) the slice overflows, wait() grows the buffer and re-runs the keypoint stages; the result
+    must be the oracle's."""
+    img = np.full((300, 400), 118, np.uint8)
+    img[:110, :150] = synth(61, 150, 110)
+    orc = oracle_mod.Oracle(oracle_mod.default_params(), threads=8).run(img)
+    ctx = gpu_hip.Context(gpu_hip.default_params())
+    ctx.debug_set(gpu_hip.DEBUG_CAND_CAP, 1024)
+    ctx.submit(img)
+    st = assert_keypoints_match(orc, ctx)
+    assert st["n_a"] > 300
+    ctx.close()

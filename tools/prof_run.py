@@ -12,5 +12,8 @@ img = synth(2, W, H)
 import json
 kw = json.loads(os.environ.get("PROF_KW", "{}"))
 ctx = hip.Context(hip.default_params(**kw))
+for item in filter(None, os.environ.get("PROF_DEBUG", "").split(",")):   # PROF_DEBUG="6:0,5:16": popsift_hip_debug_set(what, value)
+    what, value = item.split(":")
+    ctx.debug_set(int(what), int(value))
 for i in range(n):
     ctx.submit(img); c = ctx.wait(); print(c, "%.3f ms" % ctx.report().ms_device, flush=True)

@@ -8,8 +8,9 @@ One process per GPU.  Started WITHOUT a torch.distributed environment and with -
 N rank processes itself (before it has imported torch or touched HIP) and relays rank 0's line.
 
 A "step" is one pass of the extraction hot path over one batch of --batch synthetic images per GPU (inputs already
-resident in HBM; --contexts extraction contexts, each with its own HIP stream, work through the batch with one image
-in flight per context; results left device resident like the reference's FeaturesDev).  Images are independent, so
+resident in HBM; --contexts extraction contexts, each with its own HIP stream, work through the batch --launch-batch
+images at a time -- popsift_hip_submit_batch: every kernel launched once for those images; results left device
+resident like the reference's FeaturesDev).  Images are independent, so
 ranks never talk on the data path (weak scaling, no RCCL); torch.distributed is used for the barriers around the
 timed region and the MAX over ranks only.
 
@@ -17,7 +18,8 @@ Rank 0 prints ONE JSON line with the driver contract fields plus
   roofline      -- the WHOLE pipeline of one image against the HBM roofline (B_alg / T_dev, T_dev from
                    HIP events on the context's stream), with a `kernels` list: per stage its device time (HIP events
                    between the launches, C-ABI profile mode 2), share, bound, achieved / peak / frac and the HBM
-                   traffic the rocprofv3 counter passes measured for it (profiles/r02_kernel_counters.json)
+                   traffic the rocprofv3 counter passes measured for it (profiles/r03_kernel_counters.json; quoted only
+                   while the kernel sources are the ones that were counted, "counters_stale" otherwise)
   cpu_baseline  -- the CPU oracle (kind "port") on a bounded sample, N=1 only
   sparse_image  -- the same pipeline on a keypoint-sparse image (about 2 features per 1000 pixels), where the pyramid
                    -- the part `north_star` calls bandwidth-bound -- carries the time
@@ -36,6 +38,7 @@ sys.path.insert(0, HERE)
 
 W, H = 1920, 1080
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBPS = 6290.0  # ... and the read ceiling measured on the device
 VALU_PEAK_GINST = 1228.8    # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
 
 
@@ -45,8 +48,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per step per GPU (one step = one batch)")
-    ap.add_argument("--contexts", type=int, default=16, help="extraction contexts (streams) per GPU")
-    ap.add_argument("--launch-batch", type=int, default=1,
+    ap.add_argument("--contexts", type=int, default=3, help="extraction contexts (streams) per GPU")
+    ap.add_argument("--launch-batch", type=int, default=8,
                     help="images a context extracts per submit (popsift_hip_submit_batch: every kernel launched once for all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="timed loop only: no roofline / host-to-host / CPU legs (A/B runs)")
@@ -82,13 +85,17 @@ def spawn_ranks(args):
 
 def kernel_counters():
     """Per-stage HBM traffic and instruction counts from the rocprofv3 counter passes of this configuration
-    (tools/collect_profiles.sh -> profiles/r02_kernel_counters.json; FETCH_SIZE x2 + WRITE_SIZE, separate passes).
-    Counters cannot be collected inside the timed process, so the committed measurement is quoted."""
+    (tools/collect_profiles.sh -> profiles/r03_kernel_counters.json; FETCH_SIZE x2 + WRITE_SIZE, separate passes).
+    Counters cannot be collected inside the timed process, so the committed measurement is quoted -- as long as it is a
+    measurement of THESE kernels: the summary carries the hash of the kernel sources it was taken from
+    (popsift_amd/srchash.py); when the tree's differs the counters are marked stale and nothing is derived from them."""
     try:
-        with open(os.path.join(HERE, "profiles", "r02_kernel_counters.json")) as f:
-            return json.load(f)
+        with open(os.path.join(HERE, "profiles", "r03_kernel_counters.json")) as f:
+            ctr = json.load(f)
     except Exception:
-        return {}
+        return {}, True
+    from popsift_amd.srchash import kernel_source_hash
+    return ctr, ctr.get("_kernel_source_hash") != kernel_source_hash()
 
 
 class Workers:
@@ -162,10 +169,18 @@ class Workers:
 
 def b_alg(rep, w, h, in_bytes=1):
     """input read once, every Gaussian plane written and read once, every DoG plane written and read
-    once, outputs written once.  The DoG planes are not stored by this build (their consumers subtract Gaussian planes),
-    which moves fewer bytes; the survey's formula is kept as the yardstick."""
+    once, outputs written once (88 B per pyramid pixel).  The DoG planes are not stored by this build (their consumers
+    subtract Gaussian planes), which moves fewer bytes; the survey's formula is kept as the yardstick."""
     L = 6
     return w * h * in_bytes + 4.0 * rep.pyramid_pixels * (2 * L + 2 * (L - 1)) + 72.0 * rep.ext_total + 512.0 * rep.ori_total
+
+
+def b_alg_this_build(rep, w, h, in_bytes=1):
+    """The same for this build's own layout: no DoG plane is written or read; every Gaussian plane is written once and read
+    twice (by the next level and by detection; the other consumers gather) -- 12 B x L = 72 B per pyramid pixel minus the
+    first plane's missing producer read: 68 B -- plus input and outputs."""
+    L = 6
+    return w * h * in_bytes + 4.0 * rep.pyramid_pixels * (3 * L - 1) + 72.0 * rep.ext_total + 512.0 * rep.ori_total
 
 
 def single_image(ctx, ptr, hip, n=5):
@@ -292,13 +307,14 @@ def main():
         # ---- one image on an otherwise idle GPU: T_dev, stage times, pipeline roofline ------------------------------
         ms_dev, stage_ms, rep = single_image(c0, ptrs[0], hip)
         bytes_alg = b_alg(rep, W, H)
+        bytes_own = b_alg_this_build(rep, W, H)
         achieved = bytes_alg / (ms_dev * 1e-3) / 1e9
-        ctr = kernel_counters()
+        ctr, stale = kernel_counters()
         kernels = []
         ssum = sum(stage_ms) or 1.0
         for name, ms in zip(hip.STAGES, stage_ms):
             k = {"stage": name, "ms": round(ms, 4), "share": round(ms / ssum, 3)}
-            c = ctr.get(name, {})
+            c = {} if stale else ctr.get(name, {})
             k["traffic"] = c.get("hbm_bytes")
             if name in ("orientation", "descriptor", "scan"):
                 # VALU-issue bound: wave64 vector instructions per second against 1 per 2 cycles per SIMD
@@ -319,14 +335,26 @@ def main():
                     k["frac"] = round(k["achieved"] / HBM_PEAK_GBPS, 4)
             kernels.append(k)
         traffic = sum(k["traffic"] for k in kernels if k.get("traffic")) or None
+        ms_img = elapsed / (args.steps * B) * 1e3
+        valu_img = None if stale else (sum(v.get("valu_insts", 0.0) for n, v in ctr.items() if isinstance(v, dict)) or None)
         roofline = {
             "kernel": "whole pipeline, one 1920x1080 image (pyramid -> detect -> refine -> orientation -> descriptors)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "frac_of_measured_ceiling": round(achieved / HBM_MEASURED_GBPS, 4), "measured_ceiling": HBM_MEASURED_GBPS,
             "alg_bytes_per_image": bytes_alg, "ms_device": round(ms_dev, 4),
-            "steady_state": {"ms_per_image": round(elapsed / (args.steps * B) * 1e3, 4),
-                             "achieved": round(bytes_alg * args.steps * B / elapsed / 1e9, 1),
-                             "frac": round(bytes_alg * args.steps * B / elapsed / 1e9 / HBM_PEAK_GBPS, 4)},
+            # the same against this build's own compulsory traffic (no DoG planes): 68 instead of 88 B per pyramid pixel
+            "this_build": {"alg_bytes_per_image": bytes_own, "achieved": round(bytes_own / (ms_dev * 1e-3) / 1e9, 1),
+                           "frac": round(bytes_own / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                           "traffic_over_alg": round(traffic / bytes_own, 3) if traffic else None},
+            "steady_state": {"ms_per_image": round(ms_img, 4),
+                             "achieved": round(bytes_alg / (ms_img * 1e-3) / 1e9, 1),
+                             "frac": round(bytes_alg / (ms_img * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "frac_of_measured_ceiling": round(bytes_alg / (ms_img * 1e-3) / 1e9 / HBM_MEASURED_GBPS, 4),
+                             # vector instructions of all kernels of an image (counter passes) over the timed rate
+                             "valu_issue_frac": round(valu_img / (ms_img * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if valu_img else None,
+                             "hbm_traffic_frac": round(traffic / (ms_img * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None},
+            "counters": "profiles/r03_kernel_counters.json" if not stale else None, "counters_stale": stale,
             "dominant": max(kernels, key=lambda k: k["ms"])["stage"], "kernels": kernels,
         }
         extra["single_image"] = {"ms_device": round(ms_dev, 4), "features": rep.ext_total, "descriptors": rep.ori_total}
@@ -371,11 +399,10 @@ def main():
                                      "ms_device": round(ms_sp, 4), "pipeline_alg_GBps": round(bs / (ms_sp * 1e-3) / 1e9, 1),
                                      "pipeline_frac_of_8TBps": round(bs / (ms_sp * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
             sp.close()
-            # ... and its throughput with images in flight (reported extra; pyramid + detection set the pace here)
-            # four contexts: this regime is HBM-bound, more images in flight only thrash the L2s (2 / 4 / 8 / 16 contexts:
-            # 6.3 / 7.8 / 7.0 / 6.4 Gpix/s, tools/sparse_throughput.py)
-            sp_ctxs = [hip.Context(hip.default_params(threshold=0.17), device=local_rank) for _ in range(4)]
-            spw = Workers(sp_ctxs, ptrs)
+            # ... and its throughput in the configuration of the timed loop (reported extra; pyramid + detection set the
+            # pace here): 16 x 1 / 3 x 8 contexts x images per launch: 8.2 / 9.0 Gpix/s (tools/batch_sweep.sh)
+            sp_ctxs = [hip.Context(hip.default_params(threshold=0.17), device=local_rank) for _ in range(C)]
+            spw = Workers(sp_ctxs, ptrs, args.launch_batch)
             n_sp = 8
             spw.run(3)   # the single-image legs before this one leave the device idle: let the clocks come back
             torch.cuda.synchronize()
@@ -387,6 +414,7 @@ def main():
             for c in sp_ctxs:
                 c.close()
             extra["sparse_image"]["in_flight_contexts"] = len(sp_ctxs)
+            extra["sparse_image"]["images_per_launch"] = args.launch_batch
             extra["sparse_image"]["in_flight_mpix_s"] = round(n_sp * len(ptrs) * W * H / 1e6 / dt_sp, 1)
             extra["sparse_image"]["in_flight_ms_per_image"] = round(dt_sp / (n_sp * len(ptrs)) * 1e3, 4)
             extra["sparse_image"]["in_flight_pipeline_frac_of_8TBps"] = round(
@@ -425,22 +453,25 @@ def main():
                     with open(pgms[-1], "wb") as f:
                         f.write(b"P5\n%d %d\n255\n" % (W, H))
                         f.write(im.tobytes())
-                def cpp_leg(per_dev, more=()):
-                    r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(4 * per_dev * world),
-                                        "--callers", str(world), "--pgm", ",".join(pgms)] + list(more),
+                def cpp_leg(per_dev, more=(), jobs_per_submit=1):
+                    inflight = (4 * per_dev * jobs_per_submit + (8 if jobs_per_submit > 1 else 0)) * world
+                    r = subprocess.run([exe, "--images", str(64 * world), "--inflight", str(inflight),
+                                        "--callers", str(max(2, world)), "--pgm", ",".join(pgms)] + list(more),
                                        capture_output=True, text=True, timeout=180,
                                        env=dict(os.environ, POPSIFT_CONTEXTS_PER_DEVICE=str(per_dev), POPSIFT_DEVICES=devs,
+                                                POPSIFT_BATCH=str(jobs_per_submit),
                                                 # every job in flight holds ~82 MB of pinned result blocks: let the pool keep them
-                                                POPSIFT_PINNED_CACHE_MB=str(4 * per_dev * world * 100)))
+                                                POPSIFT_PINNED_CACHE_MB=str((inflight + 2 * per_dev * world + 4) * 100)))
                     out = json.loads(r.stdout.strip().splitlines()[-1])
-                    out["devices"] = devs
+                    out["devices"], out["jobs_per_submit"] = devs, jobs_per_submit
                     return out
                 extra["host_to_host_cpp_api"] = cpp_leg(4)
                 # one context per GPU: its download of image i runs under the kernels of image i+1 (fetch_begin / fetch_end)
                 extra["host_to_host_cpp_api_one_context"] = cpp_leg(1)
                 # the keypoint-sparse regime (threshold 0.17, ~2 features per 1000 px): results of a few MB per image,
                 # so the PCIe link is no longer the limit
-                extra["host_to_host_cpp_api_sparse"] = cpp_leg(4, ["--threshold", "0.17", "--images", str(256 * world)])
+                # so the PCIe link is no longer the limit; a worker takes up to 8 queued jobs per submit (POPSIFT_BATCH)
+                extra["host_to_host_cpp_api_sparse"] = cpp_leg(3, ["--threshold", "0.17", "--images", str(512 * world)], 8)
             except Exception as e:  # a reported extra: never fail the bench line over it
                 extra["host_to_host_cpp_api"] = {"error": str(e)[:200]}
         leg("cpp_api")
@@ -473,7 +504,8 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": "1920x1080 u8 grayscale, default popsift::Config (2x upscale, 9 octaves, "
                                        "3 levels, PopSift mode, loop descriptor, RootSift)",
-                           "images_per_step_per_gpu": B, "distinct_images_per_gpu": U, "in_flight_contexts_per_gpu": C,
+                           "images_per_step_per_gpu": B, "distinct_images_per_gpu": U, "contexts_per_gpu": C,
+                           "images_per_launch": args.launch_batch,
                            "results": "device resident (features + descriptors)"},
                 "features_per_s": round(feats_step * args.steps / elapsed, 1),
                 "descriptors_per_s": round(descs_step * args.steps / elapsed, 1),

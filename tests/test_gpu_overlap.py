@@ -71,3 +71,22 @@ def test_failed_slab_allocation_leaves_results_fetchable(gpu_hip):
     assert e.value.status == gpu_hip.ERR_OOM
     assert _same(ctx.fetch(), want)
     assert _same(ctx.fetch_begin().result(), want)
+
+
+@pytest.mark.gpu
+def test_a_download_drained_behind_the_handles_back_still_delivers(gpu_hip):
+    """popsift_hip_fetch_begin waits for the previous download BEFORE it allocates, so when it then fails (ERR_OOM) the
+    predecessor's data has arrived although its handle was never told; the handle's result() then gets ERR_STATE from
+    popsift_hip_fetch_end (nothing is pending any more) and must deliver all the same.  The drain is done here directly
+    through the C call -- the state a failed fetch_begin leaves."""
+    a, b = synth(44, 400, 300), synth(45, 640, 480)
+    ref = gpu_hip.Context()
+    wa, wb = ref.submit(a).fetch(), ref.submit(b).fetch()
+    ctx = gpu_hip.Context()
+    ctx.submit(a).wait()
+    pa = ctx.fetch_begin()
+    ctx.submit(b).wait()
+    assert gpu_hip.lib().popsift_hip_fetch_end(ctx._h) == gpu_hip.OK          # drained, the handle does not know
+    assert gpu_hip.lib().popsift_hip_fetch_end(ctx._h) == gpu_hip.ERR_STATE   # nothing pending
+    assert _same(pa.result(), wa)
+    assert _same(ctx.fetch(), wb)

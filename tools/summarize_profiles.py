@@ -65,11 +65,18 @@ if __name__ == "__main__":
     bench_line = [l for l in open(os.path.join(RAW, "bench.log")).read().splitlines() if l.startswith('{"metric"')][-1]
     open(os.path.join(OUT, "%s_bench_kernel_stats.txt" % TAG), "w").write(
         "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline\n"
-        "# (16 contexts in flight, 1 MI355X; includes warm-up and the single-image / profile-mode / sparse / host-to-host legs)\n"
+        "# (1 MI355X; includes warm-up and the single-image / profile-mode / sparse / host-to-host legs: for the timed loop alone see\n"
+        "#  %s_bench_quick_kernel_stats.txt)\n" % TAG
         + stats("bench") + "\n\n# bench.py output of this profiled run:\n" + bench_line + "\n")
     open(os.path.join(OUT, "%s_single_image_kernel_stats.txt" % TAG), "w").write(
         "# rocprofv3 --kernel-trace --stats -- python3 tools/prof_run.py 5   (one context, 5 x config-2 image)\n" + stats("single") +
         "\n\n# per-launch timeline of the last image\n" + timeline("single", 5) + "\n")
+    if os.path.isdir(os.path.join(RAW, "quick")):
+        qline = [l for l in open(os.path.join(RAW, "quick.log")).read().splitlines() if l.startswith("{")][-1]
+        open(os.path.join(OUT, "%s_bench_quick_kernel_stats.txt" % TAG), "w").write(
+            "# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick   (the TIMED LOOP alone: warm-up + timed steps, dense images only;\n"
+            "# a launch extracts a batch of images, so durations are per launch, not per image)\n" + stats("quick") +
+            "\n\n# bench.py --quick output of this profiled run:\n" + qline + "\n")
     allc = collections.OrderedDict()
     for sub in ("sq_inst", "sq_wait", "sq_lds", "tcc", "grbm", "fetch", "write"):
         for k, v in counters(sub).items():
@@ -94,5 +101,8 @@ if __name__ == "__main__":
                 stage[s]["kernels"].append(k)
     open(os.path.join(OUT, "%s_kernel_counters.txt" % TAG), "w").write("\n".join(lines) + "\n")
     stage["_source"] = "%s_kernel_counters.txt (rocprofv3 --pmc passes of tools/prof_run.py, per image)" % TAG
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from popsift_amd.srchash import kernel_source_hash
+    stage["_kernel_source_hash"] = kernel_source_hash()   # bench.py: counters of other kernels than the tree's are stale
     json.dump(stage, open(os.path.join(OUT, "%s_kernel_counters.json" % TAG), "w"), indent=1)
     print(json.dumps(stage)[:1500])

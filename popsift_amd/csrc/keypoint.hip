@@ -84,6 +84,14 @@ struct Taps {
     const char* up;
     __device__ __forceinline__ Taps(const float* layer, int pitch)
         : row((const char*)layer), dn((const char*)(layer + pitch)), up((const char*)(layer - pitch)) {}
+    /* the same with the BYTE offset of the element */
+    __device__ __forceinline__ void load_b(unsigned int b, float& xp, float& xm, float& yp, float& ym) const
+    {
+        xp = *(const float*)(row + (size_t)b + 4);
+        xm = *(const float*)(row + (size_t)b - 4);
+        yp = *(const float*)(dn + (size_t)b);
+        ym = *(const float*)(up + (size_t)b);
+    }
     __device__ __forceinline__ void load(int off, float& xp, float& xm, float& yp, float& ym) const
     {
         const size_t b = (unsigned int)off * 4u;
@@ -272,14 +280,20 @@ __device__ __forceinline__ float atan2_bins9(float y, float x)
     p = fmaf(p, s, 0.22938621044158936f);
     p = fmaf(p, s, -0.4205572307109833f);
     p = fmaf(p, s, 1.2730693817138672f);
-    float t = p * r;
-    t = (ay > ax) ? 2.0f - t : t;
-    t = (x < 0.0f) ? 4.0f - t : t;
-    return copysignf(t, y);
+    const float t = p * r;
+    /* octants without compares and selects (half rate; and / xor / add / sub are full rate): the angle is
+     *   2 - sx * (1 + sd * (1 - t)),   sd = -1 where |y| > |x|, sx = -1 where x < 0
+     * (2 - t where the roles of x and y were swapped, then 4 - that where x < 0), each sign applied by an XOR with
+     * the sign bit of |x| - |y| resp. of x; the sign of y is copied last.  (1 - (1 - t) differs from t by < 6e-8 bins.) */
+    const unsigned int sgn = 0x80000000u;
+    const float a = __uint_as_float(__float_as_uint(1.0f - t) ^ (__float_as_uint(ax - ay) & sgn));
+    const float b = __uint_as_float(__float_as_uint(1.0f + a) ^ (__float_as_uint(x) & sgn));
+    return copysignf(2.0f - b, y);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) fix64 lds_fix64;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
 
 /* ISA: end */
 #ifndef KP_NW
@@ -539,7 +553,8 @@ __device__ __forceinline__ DescRec make_desc_rec(const PyrDesc* __restrict__ pdp
     const float    x = e.xpos, y = e.ypos;
     const float    SBP = fabsf(DESC_MAGNIFY * e.sigma);
     const float    cell_px = (2.83f * SBP + 1.0f) * (2.83f * SBP + 1.0f);
-    const int      fbits = min(max(31 - (int)ceilf(log2f(361.0f * cell_px)), 2), 20);
+    /* ... and below 2^23 per sample (361 * 2^14 < 2^23): k_descriptor rounds by adding 2^23 */
+    const int      fbits = min(max(31 - (int)ceilf(log2f(361.0f * cell_px)), 2), 14);
     const float    csbp = cos_t * SBP, ssbp = sin_t * SBP;
     const float    bsz = fabsf(csbp) + fabsf(ssbp);
     /* union of the 16 cell boxes: cell centres reach 1.5 * bsz, each box adds bsz */
@@ -793,16 +808,22 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
     const Counters* __restrict__ ct = bd.s[blockIdx.y].ct;
     const DescRec* __restrict__ drec = bd.s[blockIdx.y].drec;
     float* __restrict__         desc = bd.s[blockIdx.y].desc;
-    __shared__ __attribute__((aligned(16))) fix64 s_hist[KP_NW][DESC_COPIES * DESC_CS];
-    /* per patch row of the current pass: flat index of its first sample (low 16 bits) | that index minus the first column
-     * of its span relative to xmin (high 16 bits, signed), so that column = flat index - (word >> 16) */
-    __shared__ unsigned int s_row[KP_NW][DESC_MAXROWS + 1];
+    /* LDS of a wave: the row records first, then the histogram copies.  The records -- per patch row of the current pass:
+     * flat index of its first sample (low 16 bits) | that index minus the first column of its span relative to xmin
+     * (high 16 bits, signed), so that column = flat index - (word >> 16) -- lie IN FRONT of the histograms so that the
+     * address of cell (-1, -1) of copy 0, which the cell arithmetic forms although no weight ever goes there (352 bytes
+     * before the copy), is still a non-negative LDS address. */
+    constexpr int ROW_WORDS = (DESC_MAXROWS + 1 + 3) & ~3; /* 132: the histograms start on a 16-byte boundary */
+    static_assert(ROW_WORDS * 4 >= 352, "cell (-1, -1) of copy 0 stays inside the wave's LDS");
+    __shared__ __attribute__((aligned(16))) unsigned int s_lds[KP_NW][ROW_WORDS + 2 * DESC_COPIES * DESC_CS];
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int     grp = lane / DESC_GL, sub = lane % DESC_GL, cpy = lane & (DESC_COPIES - 1);
-    fix64*        hall = s_hist[wave];
-    /* 32-bit LDS address of this lane's histogram copy */
-    const unsigned int hbase32 = (unsigned int)(size_t)(lds_fix64*)(hall + cpy * DESC_CS);
-    unsigned int* rinfo = s_row[wave];
+    unsigned int* rinfo = s_lds[wave];
+    fix64*        hall = (fix64*)(s_lds[wave] + ROW_WORDS);
+    /* 32-bit LDS addresses: the row records, this lane's histogram copy (as a float: the cell addresses are formed by FMAs) */
+    const unsigned int rbase32 = (unsigned int)(size_t)(lds_u32*)rinfo;
+    const float        hbasef = (float)(unsigned int)(size_t)(lds_fix64*)(hall + cpy * DESC_CS);
+    const float        cpy8f = (float)(cpy << 3);
     const int     total = min(ct->ori_total, desc_cap);
     /* rows per pass: DESC_MAXROWS, or fewer when a test asks for it (popsift_hip_debug_set DESC_ROWS) */
     const int     maxrows = min(max(sc.desc_rows, 4), DESC_MAXROWS);
@@ -893,16 +914,28 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                     carry += __shfl(incl, 63);
                 }
                 T = carry;
-                if (lane == 0) rinfo[hy] = (unsigned int)T | 0x7fff0000u;
+                /* Two sentinels close the list: a flat index at or beyond T ends up in "row" hy at column -32767 -- a sample far
+                 * outside the patch, which the in-square test drops (its taps are read at byte offset 0 of the patch: the
+                 * negative offset saturates in the conversion) -- and stops there: the record after it starts at 65535.  So
+                 * no index needs clamping and no lane needs a "past the end" flag. */
+                if (lane == 0) {
+                    rinfo[hy] = (unsigned int)T | 0x7fff0000u;
+                    rinfo[hy + 1] = 0xffffu;
+                }
             }
             wave_lds_sync();
 
             const int   loops = T;
             /* every lane group takes its own part of the list */
-            const int   quarter = (loops + DESC_GROUPS - 1) / DESC_GROUPS;
-            const int   ibeg = grp * quarter, iend = min(ibeg + quarter, loops);
-            const int   iters = (quarter + DESC_GL - 1) / DESC_GL;
-            int          row = 0;
+            /* ... a whole number of double steps each, so that no lane of a group ever walks into the next group's part: what
+             * lies beyond the list's end drops out by itself (above) */
+            const int   quarter = ((loops + DESC_GROUPS - 1) / DESC_GROUPS + 2 * DESC_GL - 1) & ~(2 * DESC_GL - 1);
+            const int   ibeg = grp * quarter;
+            const int   iters = quarter / DESC_GL;
+            /* the lane's place in the row records: LDS address of its current row's record, that row (counted from the top of
+             * the PATCH, as a float: it only feeds FMAs), the record and the one of the row below */
+            unsigned int rp = rbase32;
+            float        fr = (float)rb;
             unsigned int cur = 0;
             unsigned int nxt = 0x7fff0000u | 0xffffu;
             if (loops > 0) {
@@ -923,7 +956,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                         if (m != 0ull && grp == g) grow = rbk + __ffsll((long long)m) - 1;
                     }
                 }
-                row = rb + grow; /* rows are counted from the top of the PATCH, whatever the pass: see coord() */
+                rp = rbase32 + 4u * (unsigned int)grow;
+                fr = (float)(rb + grow); /* rows are counted from the top of the PATCH, whatever the pass: see coord() */
                 cur = rinfo[grow];
                 nxt = rinfo[grow + 1];
             }
@@ -937,29 +971,35 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
             const float  ox = (float)xmin - x, oy = (float)ymin0 - y;
             const float  u0 = fmaf(crsbp, ox, srsbp * oy), v0 = fmaf(crsbp, oy, -srsbp * ox);
             const float* corner = layer + (size_t)(ymin0 * pitch + xmin);
+            const float  pitch4f = (float)(4 * pitch);
 
             /* Two-stage software pipeline: the coordinates of the lane's next sample are computed and its four
              * gradient taps requested while the current one is being binned, so the L2 round trip of the taps
              * overlaps the arithmetic.  The loads are unconditional (in-bounds for every span position) to
-             * keep the vmcnt waits counted. */
-            auto coord = [&](int i, int& off, float& u, float& v) { /* ISA: coordinates */
+             * keep the vmcnt waits counted.
+             * What an instruction costs decides the form of everything below (tools/ubench/valu_rate.hip, MI355X): f32
+             * add / mul / FMA, 32-bit add / and / xor / arithmetic shift issue at twice the rate of compares, selects,
+             * conversions, floor, min / max, shifts-with-add and 24-bit multiplies.  So row and column enter as floats
+             * (one conversion, the row advances by a float add), and the byte offset of the taps is one FMA -- exact:
+             * 4 * (row * pitch + column) < 2^24 -- and one conversion, instead of a 24-bit multiply and a shift-add. */
+            auto coord = [&](int i, unsigned int& off, float& u, float& v) { /* ISA: coordinates */
                 /* the record of the row below the lane's current one stays in a register: no LDS read -- which would queue
                  * behind the four atomics the lane has just issued -- unless the lane moves on to another row
                  * (k_descriptor 421 -> 411 us) */
                 while (i >= (int)(nxt & 0xffffu)) {
-                    row++;
+                    fr += 1.0f;
+                    rp += 4u;
                     cur = nxt;
-                    nxt = rinfo[row + 1 - rb];
+                    nxt = *(lds_u32*)(size_t)(rp + 4u);
                 }
-                const int   c = i - ((int)cur >> 16);
-                const float fc = (float)c, fr = (float)row;
+                const float fc = (float)(i - ((int)cur >> 16));
                 u = fmaf(crsbp, fc, fmaf(srsbp, fr, u0));
                 v = fmaf(crsbp, fr, fmaf(-srsbp, fc, v0));
-                off = __mul24(row, pitch) + c;
+                off = (unsigned int)fmaf(fr, pitch4f, fc * 4.0f);
             };
             /* one sample: gradient (gx, gy) at cell-unit position (u, v) -> up to four 64-bit LDS atomics */
-            auto bin = [&](float u, float v, float gx, float gy, bool live) {
-                if (live && fabsf(u) < 2.5f && fabsf(v) < 2.5f) { /* ISA: control */
+            auto bin = [&](float u, float v, float gx, float gy) {
+                if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) { /* ISA: control */
                     /* ISA: magnitude + angle */
                     const float  mod = __builtin_amdgcn_sqrtf(fmaf(gx, gx, gy * gy));
                     /* exp(-(u^2+v^2)/8) * 2^fbits = 2^(fbits - (u^2+v^2) * log2(e)/8) */
@@ -977,71 +1017,62 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                     const float tu = u + 1.5f, tv = v + 1.5f;
                     const float fcx = floorf(tu), fcy = floorf(tv);
                     const float fx = tu - fcx, fy = tv - fcy;
-                    const int   cx0 = (int)fcx, cy0 = (int)fcy;
-                    v2f         wxx, w01;
-                    wxx.x = (cx0 >= 0) ? 1.0f - fx : 0.0f;
-                    wxx.y = (cx0 <= 2) ? fx : 0.0f;
-                    const float wy0 = (cy0 >= 0) ? (1.0f - fy) * wm : 0.0f;
-                    const float wy1 = (cy0 <= 2) ? fy * wm : 0.0f;
-                    w01.x = 1.0f - do0;
-                    w01.y = do0;
-                    /* the four cell weights as two packed products */
-#ifndef DESC_PK
-                    const v2f p0 = {wxx.x * wy0, wxx.y * wy0}, p1 = {wxx.x * wy1, wxx.y * wy1};
-#else
-                    const v2f p0 = wxx * (v2f){wy0, wy0}, p1 = wxx * (v2f){wy1, wy1};
-#endif
-                    /* byte addresses of the four words (a word is only touched when its weight is positive, and then
-                     * its cell is cx0 / cx0+1, cy0 / cy0+1 unclamped): one base, the slot of the even and of the odd
-                     * cell column, immediate offsets for the neighbours */
-                    /* slot of the lower bin: (bin + copy + 4 * (cx0 & 1)) mod 8 -- 4 * cx0 does for 4 * (cx0 & 1) under the
-                     * mask, and the bin needs no mask of its own */
-                    /* ... as 32-bit LDS byte addresses in integer arithmetic, so that the compiler can use the three-operand
-                     * forms (v_lshl_add, v_add_lshl, v_mad_i32_i24, v_xad) */
-                    const unsigned int s0 = (((unsigned int)(((int)ffo + (cx0 << 2)) + cpy)) << 3) & 56u;
-                    const unsigned int cb = (unsigned int)(__mul24(cy0, DESC_RS * 8) + (int)hbase32) + ((unsigned int)cx0 << 6);
+                    const float wx0 = 1.0f - fx, wy0 = (1.0f - fy) * wm, wy1 = fy * wm;
+                    const float w0 = 1.0f - do0;
+                    /* Byte addresses of the four words: one base, the slot of the even and of the odd cell column, immediate
+                     * offsets for the neighbours.  Slot of the lower bin: (bin + copy + 4 * (cx0 & 1)) mod 8 -- 4 * cx0 does
+                     * for 4 * (cx0 & 1) under the mask, and the bin needs no mask of its own.  Cell indices and the bin are
+                     * small integers held in floats (the floors above), so both addresses are two FMAs and ONE conversion
+                     * each -- no conversion of the three floors, no integer multiply, no shift-adds. */
+                    const unsigned int s0 = (unsigned int)(int)fmaf(fcx, 32.0f, fmaf(ffo, 8.0f, cpy8f)) & 56u;
+                    const unsigned int cb = (unsigned int)(int)fmaf(fcy, (float)(DESC_RS * 8), fmaf(fcx, 64.0f, hbasef));
                     const unsigned int e0 = cb + s0;
                     const unsigned int e1 = (s0 ^ 32u) + cb;
+                    /* A cell that does not exist (column / row -1 or 4) is skipped by the exec mask of its atomic -- the four
+                     * compares below ARE the existence tests; its weight is not zeroed first, and no weight is tested against
+                     * zero (an add of zero is harmless): four compares per sample where there were eight and four selects. */
+                    const bool x0 = tu >= 0.0f, x1 = tu < 3.0f, y0 = tv >= 0.0f, y1 = tv < 3.0f;
 /* ISA: atomics */
-#ifndef DESC_PK
-#define DESC_PKFMA(W, G) ((v2f){fmaf((W).x, (G), 0.5f), fmaf((W).y, (G), 0.5f)})
-#else
-#define DESC_PKFMA(W, G) __builtin_elementwise_fma((W), (v2f){(G), (G)}, (v2f){0.5f, 0.5f})
-#endif
-#define PS_CELL(ADDR, WGT)                                                                              \
-    {                                                                                                   \
-        const float wgt = (WGT);                                                                        \
-        if (wgt > 0.0f) {                                                                               \
-            const v2f f = DESC_PKFMA(w01, wgt);                                                         \
-            __hip_atomic_fetch_add((lds_fix64*)(size_t)(ADDR), ((fix64)(unsigned int)f.y << 32) | (fix64)(unsigned int)f.x, \
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                      \
-        }                                                                                               \
+/* round(w * wgt) for both halves of the word by the float trick: w * wgt + 2^23 holds the integer in its mantissa (the
+ * products stay below 2^23: make_desc_rec keeps fbits <= 14), one v_and strips the exponent -- an FMA and an AND, both
+ * full rate, where v_cvt_u32_f32 runs at half rate */
+#define PS_CELL(ADDR, WGT)                                                                                     \
+    {                                                                                                          \
+        const float        wgt = (WGT);                                                                        \
+        const unsigned int lo = __float_as_uint(fmaf(w0, wgt, 8388608.0f)) & 0x7fffffu;                        \
+        const unsigned int hi = __float_as_uint(fmaf(do0, wgt, 8388608.0f)) & 0x7fffffu;                       \
+        __hip_atomic_fetch_add((lds_fix64*)(size_t)(ADDR), ((fix64)hi << 32) | (fix64)lo, __ATOMIC_RELAXED,    \
+                               __HIP_MEMORY_SCOPE_WORKGROUP);                                                  \
     }
-                    PS_CELL(e0, p0.x)
-                    PS_CELL(e1 + 64u, p0.y)
-                    PS_CELL(e0 + DESC_RS * 8u, p1.x)
-                    PS_CELL(e1 + DESC_RS * 8u + 64u, p1.y)
+                    if (y0) {
+                        if (x0) PS_CELL(e0, wy0 * wx0)
+                        if (x1) PS_CELL(e1 + 64u, wy0 * fx)
+                    }
+                    if (y1) {
+                        if (x0) PS_CELL(e0 + DESC_RS * 8u, wy1 * wx0)
+                        if (x1) PS_CELL(e1 + DESC_RS * 8u + 64u, wy1 * fx)
+                    }
 #undef PS_CELL
                 }
             };
             /* ISA: control */
             /* two register sets take turns as "being binned" and "in flight" (the loop is unrolled by two so that no
              * value has to be copied from one role to the other) */
-            int   off_a = 0, off_b = 0;
+            unsigned int off_a = 0, off_b = 0;
             float u_a = 3.0f, v_a = 3.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
             float u_b = 3.0f, v_b = 3.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
             const Taps taps(corner, pitch);
             if (loops > 0) {
-                coord(min(ibeg + sub, loops - 1), off_a, u_a, v_a);
-                taps.load(off_a, a0, a1, a2, a3);
+                coord(ibeg + sub, off_a, u_a, v_a);
+                taps.load_b(off_a, a0, a1, a2, a3);
             }
             for (int t = 0, i = ibeg + sub; t < iters; t += 2, i += 2 * DESC_GL) {
-                coord(min(i + DESC_GL, loops - 1), off_b, u_b, v_b);
-                taps.load(off_b, b0, b1, b2, b3);
-                bin(u_a, v_a, a0 - a1, a2 - a3, i < iend);
-                coord(min(i + 2 * DESC_GL, loops - 1), off_a, u_a, v_a);
-                taps.load(off_a, a0, a1, a2, a3);
-                bin(u_b, v_b, b0 - b1, b2 - b3, i + DESC_GL < iend);
+                coord(i + DESC_GL, off_b, u_b, v_b);
+                taps.load_b(off_b, b0, b1, b2, b3);
+                bin(u_a, v_a, a0 - a1, a2 - a3);
+                coord(i + 2 * DESC_GL, off_a, u_a, v_a);
+                taps.load_b(off_a, a0, a1, a2, a3);
+                bin(u_b, v_b, b0 - b1, b2 - b3);
             }
             wave_lds_sync(); /* ISA: end */
             } /* passes */

@@ -19,8 +19,15 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(R, "popsift_amd", "csrc", "keypoint.hip")
-QUARTER = ("v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_mul_lo_u32",
-           "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32", "v_rcp_iflag_f32", "v_sqrt_f64", "v_rcp_f64")
+# Issue cost classes measured on MI355X (tools/ubench/valu_rate.hip, cycles per wave64 instruction with 8 waves on a SIMD):
+#   full rate 1.34 -- f32 add / sub / mul / FMA (also with a literal), 32-bit add / sub, and / or / xor, arithmetic shift right, mov
+#   half rate 2.36 -- compares, v_cndmask, conversions, floor / fract / trunc, min / max / max3, v_bfi, shifts left, v_lshl_add /
+#                     v_add_lshl / v_lshl_or / v_add3, 24- and 32-bit multiplies and multiply-adds
+#   transcendental 4.64 -- sqrt, rcp, rsq, exp, log, sin, cos
+TRANS = ("v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32")
+FULL = ("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32",
+        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_ashrrev_i32", "v_mov_b32", "v_not_b32")
+COST = {"valu": 1.0, "valu_half": 2.36 / 1.34, "valu_quarter": 4.64 / 1.34}
 
 
 def source_groups():
@@ -120,7 +127,9 @@ def main():
                 continue
             op = t.split()[0]
             if op.startswith("v_"):
-                k = "valu_quarter" if op.startswith(QUARTER) else "valu"
+                base = op[:-4] if op.endswith(("_e32", "_e64")) else op
+                base = base.replace("_sdwa", "").replace("_dpp", "")
+                k = "valu_quarter" if base in TRANS else ("valu" if base in FULL else "valu_half")
             elif op.startswith("s_waitcnt") or op.startswith("s_nop"):
                 k = "wait_nop"
             elif op.startswith("s_"):
@@ -138,16 +147,18 @@ def main():
     print("# %s: loop %s (depth %d), %d blocks, body handles %d sample(s); flags: %s" %
           (kernel, hdr, depth, len(member), samples, " ".join(extra) or "(Makefile)"))
     print("# " + "  ".join(x.strip("; ").strip() for x in vg))
-    tot_v = kinds["valu"] + kinds["valu_quarter"]
-    # issue cost on gfx950 (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): transcendentals 8 cycles against 4
-    print("per sample: VALU %.1f (of which transcendental / 32-bit multiply %.1f => %.1f plain-VALU issue slots)  SALU %.1f  LDS %.1f  VMEM %.1f  waits/nops %.1f"
-          % (tot_v / samples, kinds["valu_quarter"] / samples, (kinds["valu"] + 2 * kinds["valu_quarter"]) / samples,
+    tot_v = kinds["valu"] + kinds["valu_half"] + kinds["valu_quarter"]
+    cost = sum(kinds[k] * c for k, c in COST.items())
+    print("per sample: VALU %.1f = %.1f full-rate + %.1f half-rate + %.1f transcendental => %.1f full-rate issue slots;  SALU %.1f  LDS %.1f  VMEM %.1f  waits/nops %.1f"
+          % (tot_v / samples, kinds["valu"] / samples, kinds["valu_half"] / samples, kinds["valu_quarter"] / samples, cost / samples,
              kinds["salu"] / samples, kinds["lds"] / samples, kinds["vmem"] / samples, kinds["wait_nop"] / samples))
-    print("\n%-22s %8s %8s %8s %8s %8s" % ("group (per sample)", "VALU", "slow", "SALU", "LDS", "VMEM"))
-    for g in sorted(bygroup, key=lambda g: -(bygroup[g]["valu"] + bygroup[g]["valu_quarter"])):
+    print("\n%-22s %8s %8s %8s %8s %8s %8s %8s" % ("group (per sample)", "VALU", "half", "transc", "slots", "SALU", "LDS", "VMEM"))
+    tv = lambda c: c["valu"] + c["valu_half"] + c["valu_quarter"]
+    for g in sorted(bygroup, key=lambda g: -tv(bygroup[g])):
         c = bygroup[g]
-        print("%-22s %8.1f %8.1f %8.1f %8.1f %8.1f" % (g, (c["valu"] + c["valu_quarter"]) / samples, c["valu_quarter"] / samples,
-                                                     c["salu"] / samples, c["lds"] / samples, c["vmem"] / samples))
+        print("%-22s %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f" % (g, tv(c) / samples, c["valu_half"] / samples, c["valu_quarter"] / samples,
+                                                                 sum(c[k] * w for k, w in COST.items()) / samples,
+                                                                 c["salu"] / samples, c["lds"] / samples, c["vmem"] / samples))
     if os.environ.get("ISA_LIST"):
         print()
         for n, lc, g, t in listing:

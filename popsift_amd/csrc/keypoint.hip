@@ -798,7 +798,15 @@ constexpr int DESC_RS = 36;                /* words per cell row */
 constexpr int DESC_CS = 3 * DESC_RS + 32;  /* words per copy (the last row needs no padding): 140 */
 constexpr int DESC_MAXROWS = 128; /* patch rows handled by the span path */
 #ifndef DESC_GROUPS
-#define DESC_GROUPS 4 /* lane groups, each on its own 1 / DESC_GROUPS of the sample list */
+/* Lane groups, each on its own 1 / DESC_GROUPS of the sample list.  Round 2 ran FOUR (16 lanes each, on four distant
+ * parts of the patch: fewer lanes of a wave fall into one cell, 61 % fewer LDS bank conflicts) while the kernel was bound
+ * by vector issue and LDS.  Round 3 took a fifth of the issue slots out of the loop, and what bound the kernel next was the
+ * L1 -> L2 request stream of its taps (L1 hit rate 68 %, the L1 stalled on pending data 46 % of the time,
+ * tools/desc_batch_counters.sh): four streams touch four times the cache lines per wave step.  ONE group -- 64 lanes on
+ * 64 consecutive samples, i.e. on one and a half to two neighbouring patch rows, whose up / down taps are each other's
+ * centre rows -- leaves the kernel's own time unchanged and makes the timed loop 4.8 % faster (1 / 2 / 4 / 8 groups:
+ * 3.36 / 3.36 / 3.20 / 2.74 Gpix/s): the requests it no longer makes are L2 bandwidth for the kernels beside it. */
+#define DESC_GROUPS 1
 #endif
 constexpr int DESC_GL = 64 / DESC_GROUPS; /* lanes per group */
 

@@ -242,6 +242,19 @@ __device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
     c = (float)(((n + 1) & 2) ? -cd : cd);
 }
 
+/* t = atan(min / max) * 4/pi in [0, 1] -> the angle of (x, y) in (-4, 4], without compares and selects (half rate on
+ * gfx950; and / xor / add / sub are full rate, tools/ubench/valu_rate.hip):
+ *   2 - sx * (1 + sd * (1 - t)),   sd = -1 where |y| > |x|, sx = -1 where x < 0
+ * (2 - t where the roles of x and y were swapped, then 4 - that where x < 0), each sign applied by an XOR with the sign
+ * bit of |x| - |y| resp. of x; the sign of y is copied last (one v_bfi).  1 - (1 - t) differs from t by < 6e-8. */
+__device__ __forceinline__ float octants(float t, float x, float y, float ax, float ay)
+{
+    const unsigned int sgn = 0x80000000u;
+    const float a = __uint_as_float(__float_as_uint(1.0f - t) ^ (__float_as_uint(ax - ay) & sgn));
+    const float b = __uint_as_float(__float_as_uint(1.0f + a) ^ (__float_as_uint(x) & sgn));
+    return copysignf(2.0f - b, y);
+}
+
 /* atan2(y, x) * 4/pi in (-4, 4]: octant reduction + odd degree-11 minimax polynomial of
  * atan(r) * 4/pi on [0, 1] (max error 2.2e-6 bins = 1.7e-6 rad, fitted offline), v_rcp instead of
  * a division.  Only used for the descriptor's SOFT orientation binning, which is continuous in
@@ -260,10 +273,7 @@ __device__ __forceinline__ float atan2_bins(float y, float x)
     p = fmaf(p, s, 0.24642325937747955f);
     p = fmaf(p, s, -0.42350852489471436f);
     p = fmaf(p, s, 1.2732105255126953f);
-    float t = p * r;
-    t = (ay > ax) ? 2.0f - t : t;
-    t = (x < 0.0f) ? 4.0f - t : t;
-    return copysignf(t, y);
+    return octants(p * r, x, y, ax, ay);
 }
 
 /* The same with a degree-9 polynomial (max error 1.5e-5 bins = 1.2e-5 rad, fitted offline as a minimax problem) for the
@@ -280,15 +290,7 @@ __device__ __forceinline__ float atan2_bins9(float y, float x)
     p = fmaf(p, s, 0.22938621044158936f);
     p = fmaf(p, s, -0.4205572307109833f);
     p = fmaf(p, s, 1.2730693817138672f);
-    const float t = p * r;
-    /* octants without compares and selects (half rate; and / xor / add / sub are full rate): the angle is
-     *   2 - sx * (1 + sd * (1 - t)),   sd = -1 where |y| > |x|, sx = -1 where x < 0
-     * (2 - t where the roles of x and y were swapped, then 4 - that where x < 0), each sign applied by an XOR with
-     * the sign bit of |x| - |y| resp. of x; the sign of y is copied last.  (1 - (1 - t) differs from t by < 6e-8 bins.) */
-    const unsigned int sgn = 0x80000000u;
-    const float a = __uint_as_float(__float_as_uint(1.0f - t) ^ (__float_as_uint(ax - ay) & sgn));
-    const float b = __uint_as_float(__float_as_uint(1.0f + a) ^ (__float_as_uint(x) & sgn));
-    return copysignf(2.0f - b, y);
+    return octants(p * r, x, y, ax, ay);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -317,7 +319,10 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
     const InitExt* __restrict__ iext = filtered ? bd.s[blockIdx.y].iext2 : bd.s[blockIdx.y].iext;
     float* __restrict__         ohist = bd.s[blockIdx.y].ohist;
     const int n_oct = pdp->n_oct, L = pdp->L;
-    __shared__ fix64 s_hist[KP_NW][ORI_COPIES][PS_ORI_NBINS];
+    /* bin 36 is bin 0 (the histogram is circular): a sample that rounds up to 36 is added there and joins bin 0 at the
+     * read-out, so the loop needs no wrap-around select */
+    constexpr int    NB = PS_ORI_NBINS + 2;
+    __shared__ fix64 s_hist[KP_NW][ORI_COPIES][NB];
     const int        wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     fix64*           hall = &s_hist[wave][0][0];
     fix64*           hist = s_hist[wave][lane & (ORI_COPIES - 1)];
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         const int      lvl = uniform(min(max(ie.lpos, 0), L - 1));
         const float*   layer = arena + uniform64(od->data_off + lvl * od->plane_stride);
 
-        for (int k = lane; k < ORI_COPIES * PS_ORI_NBINS; k += 64) hall[k] = 0ull;
+        for (int k = lane; k < ORI_COPIES * NB; k += 64) hall[k] = 0ull;
         wave_lds_sync();
 
         const float x = uniformf(ie.xpos), y = uniformf(ie.ypos), sig = uniformf(ie.sigma);
@@ -354,20 +359,28 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         const int   wx = xmax - xmin + 1;
         const int   hy = ymax - ymin + 1;
         const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
-        /* row of flat index i = (int)((i + 0.5) / wx): the half keeps the quotient at least 0.5 / wx away from an integer,
+        /* row of flat index i = floor((i + 0.5) / wx): the half keeps the quotient at least 0.5 / wx away from an integer,
          * far more than the ulp by which v_rcp may miss 1 / wx, so the approximate reciprocal gives the exact row */
         const float inv_wx = __builtin_amdgcn_rcpf((float)max(wx, 1));
+        const float wxf = (float)wx, xminf = (float)xmin, yminf = (float)ymin, pitch4f = (float)(4 * pitch);
+        const float* corner = layer + (size_t)(ymin * pitch + xmin);
 
-        /* software pipeline as in k_descriptor: request the taps of sample i+64 while binning sample i */
-        auto coord = [&](int i, int& xx, int& yy) {
-            const int row = (int)(((float)i + 0.5f) * inv_wx);
-            yy = row + ymin;
-            xx = i - __mul24(row, wx) + xmin;
+        /* software pipeline as in k_descriptor: request the taps of sample i+64 while binning sample i.  Row, column
+         * and the byte offset of the taps are formed in floats (exact small integers): one conversion, one floor and FMAs
+         * instead of two conversions, two 24-bit multiplies and a shift-add -- half-rate instructions on gfx950
+         * (tools/ubench/valu_rate.hip).  (fx, fy) = the pixel, as the floats the reference converts its ints to. */
+        auto coord = [&](int i, float& fx, float& fy, unsigned int& off) {
+            const float fi = (float)i;
+            const float frow = floorf((fi + 0.5f) * inv_wx);
+            const float fcol = fmaf(-frow, wxf, fi);
+            fx = fcol + xminf;
+            fy = frow + yminf;
+            off = (unsigned int)fmaf(frow, pitch4f, fcol * 4.0f);
         };
-        /* one sample: pixel (xx, yy) with gradient (gdx, gdy) -> at most one fixed-point LDS atomic */
-        auto bin = [&](int xx, int yy, float gdx, float gdy, bool live) {
-            const float dx = xx - x;
-            const float dy = yy - y;
+        /* one sample: pixel (fx, fy) with gradient (gdx, gdy) -> at most one fixed-point LDS atomic */
+        auto bin = [&](float fx, float fy, float gdx, float gdy, bool live) {
+            const float dx = fx - x;
+            const float dy = fy - y;
             /* int truncation, s_orientation.cu:123 -- as a float (the values are far below 2^24, so truncf, the
              * comparison with rad^2 and the product with `factor` give what the int round trip gives) */
             const float sq_dist = truncf(dx * dx + dy * dy);
@@ -379,37 +392,33 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
                  * bin edge: the cheap atan2 (the descriptor's one-reciprocal degree-11 polynomial in units of pi / 4:
                  * error < 1.7e-6 rad = 1e-5 of these bins) decides every sample farther than 1e-4 bins from an edge
                  * identically to the accurate one, which the others (1 in 5000) then take. */
-                float fb = (atan2_bins(gdy, gdx) + 4.0f) * ((float)PS_ORI_NBINS / 8.0f);
-                float fl = floorf(fb), fr = fb - fl;
+                float fb = fmaf(atan2_bins(gdy, gdx), (float)PS_ORI_NBINS / 8.0f, (float)PS_ORI_NBINS / 2.0f);
                 /* next to an edge the value is formed exactly as the oracle forms it (product, then IEEE quotient): gradients
                  * of exactly 45 degrees -- frequent in level 0 of the up-scaled octave -- sit ON the edge 22.5, 31.5, ...,
                  * where the two formulas round to different sides */
-                if (fabsf(fr - 0.5f) < 1e-4f) {
-                    fb = (float)PS_ORI_NBINS * (atan2_acc(gdy, gdx) + F_PI) / F_PI2;
-                    fl = floorf(fb);
-                    fr = fb - fl;
-                }
-                /* roundf(fb) for fb >= 0: the floor, plus one from the half on (fb - floor is exact) */
-                int bidx = (int)fl + (fr >= 0.5f ? 1 : 0);
-                bidx = (bidx == PS_ORI_NBINS) ? 0 : bidx;
-                if (bidx >= 0 && bidx < PS_ORI_NBINS) atomicAdd(&hist[bidx], (fix64)(unsigned int)wfix);
+                if (fabsf((fb - floorf(fb)) - 0.5f) < 1e-4f) fb = (float)PS_ORI_NBINS * (atan2_acc(gdy, gdx) + F_PI) / F_PI2;
+                /* roundf(fb) for fb in [0, 36]: floor(fb + 0.5), one instruction; 36 is bin 0 (NB above) */
+                int bidx;
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(bidx) : "v"(fb));
+                atomicAdd(&hist[bidx], (fix64)(unsigned int)wfix);
             }
         };
         /* two register sets take turns as "being binned" and "in flight", as in k_descriptor (unrolled by two, so no
          * value is copied from one role to the other) */
-        int   xa = xmin, ya = ymin, xb = xmin, yb = ymin;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
-        const Taps taps(layer, pitch);
+        float        xa = 0.0f, ya = 0.0f, xb = 0.0f, yb = 0.0f;
+        unsigned int oa = 0, ob = 0;
+        float        a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+        const Taps   taps(corner, pitch);
         if (loops > 0) {
-            coord(min(lane, loops - 1), xa, ya);
-            taps.load(__mul24(ya, pitch) + xa, a0, a1, a2, a3);
+            coord(min(lane, loops - 1), xa, ya, oa);
+            taps.load_b(oa, a0, a1, a2, a3);
         }
         for (int i = lane; i < loops; i += 128) {
-            coord(min(i + 64, loops - 1), xb, yb);
-            taps.load(__mul24(yb, pitch) + xb, b0, b1, b2, b3);
+            coord(min(i + 64, loops - 1), xb, yb, ob);
+            taps.load_b(ob, b0, b1, b2, b3);
             bin(xa, ya, a0 - a1, a2 - a3, true);
-            coord(min(i + 128, loops - 1), xa, ya);
-            taps.load(__mul24(ya, pitch) + xa, a0, a1, a2, a3);
+            coord(min(i + 128, loops - 1), xa, ya, oa);
+            taps.load_b(oa, a0, a1, a2, a3);
             bin(xb, yb, b0 - b1, b2 - b3, i + 64 < loops);
         }
         wave_lds_sync();
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         if (lane < PS_ORI_NBINS) {
             fix64 acc = 0ull;
 #pragma unroll
-            for (int k = 0; k < ORI_COPIES; k++) acc += hall[k * PS_ORI_NBINS + lane];
+            for (int k = 0; k < ORI_COPIES; k++) acc += hall[k * NB + lane] + (lane == 0 ? hall[k * NB + PS_ORI_NBINS] : 0ull);
             ohist[(size_t)g * PS_ORI_NBINS + lane] = from_fix(acc);
         }
         wave_lds_sync();

@@ -242,6 +242,7 @@ __device__ __forceinline__ void sincos_cr(float ang, float& s, float& c)
     c = (float)(((n + 1) & 2) ? -cd : cd);
 }
 
+/* ISA: magnitude + angle */
 /* t = atan(min / max) * 4/pi in [0, 1] -> the angle of (x, y) in (-4, 4], without compares and selects (half rate on
  * gfx950; and / xor / add / sub are full rate, tools/ubench/valu_rate.hip):
  *   2 - sx * (1 + sd * (1 - t)),   sd = -1 where |y| > |x|, sx = -1 where x < 0

@@ -26,7 +26,8 @@ SRC = os.path.join(R, "popsift_amd", "csrc", "keypoint.hip")
 #   transcendental 4.64 -- sqrt, rcp, rsq, exp, log, sin, cos
 TRANS = ("v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32")
 FULL = ("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32",
-        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_ashrrev_i32", "v_mov_b32", "v_not_b32")
+        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_ashrrev_i32", "v_lshrrev_b32", "v_mov_b32",
+        "v_not_b32")
 COST = {"valu": 1.0, "valu_half": 2.36 / 1.34, "valu_quarter": 4.64 / 1.34}
 
 

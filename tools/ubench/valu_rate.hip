@@ -61,7 +61,23 @@ constexpr int ITERS = 256; /* x 8 statements x 8 instructions = 16384 instructio
 #define F_FMAAK(i) "v_fmaak_f32 %" #i ", %8, %" #i ", 0x3e7c5661"
 #define F_SUBABS(i) "v_sub_f32_e64 %" #i ", 1.0, |%" #i "|"
 #define F_CMPABS(i) "v_cmp_lt_f32_e64 s[20:21], |%" #i "|, %8"
-#define F_PKFMA(i) "v_pk_fma_f32 %[p" #i "], %[p" #i "], %[p" #i "], %[p" #i "]"
+#define F_OR(i) "v_or_b32 %" #i ", %8, %" #i
+#define F_LSHR(i) "v_lshrrev_b32 %" #i ", 5, %" #i
+#define F_SUBU(i) "v_sub_u32 %" #i ", %8, %" #i
+#define F_SUBF(i) "v_sub_f32 %" #i ", %8, %" #i
+#define F_MINI(i) "v_min_i32 %" #i ", %8, %" #i
+#define F_FRACT(i) "v_fract_f32 %" #i ", %" #i
+#define F_TRUNC(i) "v_trunc_f32 %" #i ", %" #i
+#define F_CVTRPI(i) "v_cvt_rpi_i32_f32 %" #i ", %" #i
+#define F_CVTFLR(i) "v_cvt_flr_i32_f32 %" #i ", %" #i
+#define F_CVTUB(i) "v_cvt_f32_ubyte0 %" #i ", %" #i
+#define F_CNDS(i) "v_cndmask_b32 %" #i ", %8, %" #i ", s[22:23]"
+#define F_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 3, 5"
+#define F_MULU24(i) "v_mul_u32_u24 %" #i ", %8, %" #i
+#define F_NOT(i) "v_not_b32 %" #i ", %" #i
+#define F_MED3(i) "v_med3_f32 %" #i ", %8, %9, %" #i
+#define F_LDEXP(i) "v_ldexp_f32 %" #i ", %" #i ", 2"
+#define F_MOVDPP(i) "v_mov_b32_dpp %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 
 K1(k_fma, F_FMA) K1(k_fmac, F_FMAC) K1(k_mul, F_MUL) K1(k_add, F_ADD) K1(k_max3, F_MAX3) K1(k_min, F_MIN) K1(k_floor, F_FLOOR)
 K1(k_cvti, F_CVTI) K1(k_cvtf, F_CVTF) K1(k_cvtu, F_CVTU) K1(k_cndmask, F_CNDM) K1(k_cmp_vcc, F_CMP) K1(k_cmp_sgpr, F_CMPS)
@@ -69,6 +85,26 @@ K1(k_addu, F_ADDU) K1(k_add3, F_ADD3) K1(k_lshl_add, F_LSHLADD) K1(k_add_lshl, F
 K1(k_mad24, F_MAD24) K1(k_mullo, F_MULLO) K1(k_and, F_AND) K1(k_xor, F_XOR) K1(k_bfi, F_BFI) K1(k_ashr, F_ASHR)
 K1(k_lshl, F_LSHL) K1(k_mov, F_MOV) K1(k_sqrt, F_SQRT) K1(k_rcp, F_RCP) K1(k_exp, F_EXP) K1(k_fmaak, F_FMAAK)
 K1(k_sub_abs, F_SUBABS) K1(k_cmp_abs, F_CMPABS)
+K1(k_or, F_OR) K1(k_lshr, F_LSHR) K1(k_subu, F_SUBU) K1(k_subf, F_SUBF) K1(k_mini, F_MINI) K1(k_fract, F_FRACT) K1(k_trunc, F_TRUNC)
+K1(k_cvtrpi, F_CVTRPI) K1(k_cvtflr, F_CVTFLR) K1(k_cvtub, F_CVTUB) K1(k_cnds, F_CNDS) K1(k_bfe, F_BFE) K1(k_mulu24, F_MULU24)
+K1(k_not, F_NOT) K1(k_med3, F_MED3) K1(k_ldexp, F_LDEXP) K1(k_movdpp, F_MOVDPP)
+// packed f32: two lanes' worth of work per instruction on register pairs
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define PKBODY(INS)                                                                                        \
+    for (int it = 0; it < ITERS; it++) {                                                                   \
+        REP8(asm volatile(INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" INS : "+v"(q0) : "v"(qa)); ) \
+    }
+#define PKKERNEL(NAME, INS)                                                                      \
+    __global__ __launch_bounds__(64) void NAME(long long* out, float a, float b)                  \
+    {                                                                                             \
+        v2f q0 = {(float)threadIdx.x, a}, qa = {a, b};                                            \
+        const long long t0 = __builtin_readcyclecounter();                                       \
+        PKBODY(INS)                                                                               \
+        const long long t1 = __builtin_readcyclecounter();                                       \
+        if (q0.x + q0.y == 12345.678f) out[0] = 1;                                                \
+        if (threadIdx.x == 0) out[1 + blockIdx.x] = t1 - t0;                                      \
+    }
+PKKERNEL(k_pkfma, "v_pk_fma_f32 %0, %1, %1, %0") PKKERNEL(k_pkmul, "v_pk_mul_f32 %0, %1, %0") PKKERNEL(k_pkadd, "v_pk_add_f32 %0, %1, %0")
 // a typical mix: compare -> select (vcc dependency inside the wave)
 KERNEL(k_cmp_cnd, F_CMP(0), F_CNDM(0), F_CMP(1), F_CNDM(1), F_CMP(2), F_CNDM(2), F_CMP(3), F_CNDM(3))
 KERNEL(k_fma_int, F_FMA(0), F_ADDU(1), F_FMA(2), F_ADDU(3), F_FMA(4), F_ADDU(5), F_FMA(6), F_ADDU(7))
@@ -90,7 +126,12 @@ int main()
         {"v_add_lshl_u32", k_add_lshl}, {"v_mul_i32_i24", k_mul24}, {"v_mad_u32_u24", k_mad24}, {"v_mul_lo_u32", k_mullo},
         {"v_and_b32", k_and}, {"v_xor_b32", k_xor}, {"v_bfi_b32", k_bfi}, {"v_ashrrev_i32", k_ashr}, {"v_lshlrev_b32", k_lshl},
         {"v_mov_b32", k_mov}, {"v_sqrt_f32", k_sqrt}, {"v_rcp_f32", k_rcp}, {"v_exp_f32", k_exp}, {"v_fmaak_f32 (literal)", k_fmaak},
-        {"v_sub_f32 1.0 - |x| (VOP3)", k_sub_abs}, {"pair: v_cmp -> v_cndmask", k_cmp_cnd}, {"pair: v_fma_f32 + v_add_u32", k_fma_int}};
+        {"v_sub_f32 1.0 - |x| (VOP3)", k_sub_abs}, {"pair: v_cmp -> v_cndmask", k_cmp_cnd}, {"pair: v_fma_f32 + v_add_u32", k_fma_int},
+        {"v_or_b32", k_or}, {"v_lshrrev_b32", k_lshr}, {"v_sub_u32", k_subu}, {"v_sub_f32", k_subf}, {"v_min_i32", k_mini},
+        {"v_fract_f32", k_fract}, {"v_trunc_f32", k_trunc}, {"v_cvt_rpi_i32_f32", k_cvtrpi}, {"v_cvt_flr_i32_f32", k_cvtflr},
+        {"v_cvt_f32_ubyte0", k_cvtub}, {"v_cndmask_b32 (sgpr mask)", k_cnds}, {"v_bfe_u32", k_bfe}, {"v_mul_u32_u24", k_mulu24},
+        {"v_not_b32", k_not}, {"v_med3_f32", k_med3}, {"v_ldexp_f32", k_ldexp}, {"v_mov_b32 dpp quad_perm", k_movdpp},
+        {"v_pk_fma_f32 (dependent chain)", k_pkfma}, {"v_pk_mul_f32 (dependent chain)", k_pkmul}, {"v_pk_add_f32 (dependent chain)", k_pkadd}};
     const long long n_ins = (long long)ITERS * 64;
     printf("%-30s %s\n", "instruction", "SIMD cycles per wave64 instruction at 1 / 2 / 4 / 8 waves per SIMD");
     for (auto& e : ks) {

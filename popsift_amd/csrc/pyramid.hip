@@ -606,14 +606,17 @@ int blur_tile_w() { return TW; }
 int blur_tile_h(int w, int h)
 {
     constexpr long min_tiles = 512;
+    /* (per image: counting the tiles of all images of a batch -- 64-row tiles for octaves 1 and 2 of a batch of eight 1080p
+     * images -- measured 0.7 % slower) */
     const long tiles64 = (long)((w + TW - 1) / TW) * ((h + 63) / 64);
     return tiles64 >= min_tiles ? 64 : 32;
 }
 
 /* lanes per 4x4 block for small planes: 1 / 2 / 4 -> pyramid stage of a 1080p image 291 / 295 / 275 us */
 constexpr int BLUR_SMALL_LP = 4;
-/* a plane whose level launch is one round of workgroups (at most one 128 x 32 tile per CU): latency, not throughput */
-bool blur_is_small(int w, int h) { return (long)((w + TW - 1) / TW) * ((h + 31) / 32) <= 256; }
+/* planes whose level launch -- for all nb images of the batch -- is one round of workgroups (at most one 128 x 32 tile per
+ * CU): latency, not throughput */
+bool blur_is_small(int w, int h, int nb) { return (long)((w + TW - 1) / TW) * ((h + 31) / 32) * nb <= 256; }
 
 /* both planes with 32-row tiles and plane-to-plane filtering (mode 0); more lanes per tile when both planes are small
  * and no DoG is stored */
@@ -621,7 +624,7 @@ hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int
 {
     const int halo = std::max(span_a, span_b) - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    const bool small = a.dog_off < 0 && b.dog_off < 0 && blur_is_small(a.w, a.h) && blur_is_small(b.w, b.h) && halo <= 16;
+    const bool small = a.dog_off < 0 && b.dog_off < 0 && blur_is_small(a.w, a.h, nb) && blur_is_small(b.w, b.h, nb) && halo <= 16;
     const dim3 grid(a.tiles_x * a.tiles_y + b.tiles_x * b.tiles_y, nb), block(small ? 256 * BLUR_SMALL_LP : 256);
 #define PS_CASE(H)                                                                     \
     if (halo <= H) {                                                                   \
@@ -676,7 +679,7 @@ hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode,
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    if (mode == 0 && tile_h == 32 && a.dog_off < 0 && halo <= 16 && blur_is_small(a.w, a.h)) return launch_blur_small(a, bd, nb, halo, s);
+    if (mode == 0 && tile_h == 32 && a.dog_off < 0 && halo <= 16 && blur_is_small(a.w, a.h, nb)) return launch_blur_small(a, bd, nb, halo, s);
     /* the 27-tap level of a large plane: 512 lanes, two per 4x4 block -- every lane filters half the rows of the
      * throughput shape and the tile keeps its LDS footprint (24.9 instead of 27.1 us per 3840 x 2160 launch; 1024 lanes
      * with two or four per block: 27.6 / 28.3 us) */

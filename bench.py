@@ -259,6 +259,7 @@ def main():
     seeds = [2 if (rank == 0 and k == 0) else 100 + i for k, i in enumerate(mine)]
     host_imgs = [synth(s, W, H) for s in seeds]
     leg("synth")
+
     dev_imgs = [torch.from_numpy(im).cuda(local_rank) for im in host_imgs]  # inputs resident in HBM
     ptrs = [dev_imgs[i % U].data_ptr() for i in range(B)]
     C = max(1, min(args.contexts, B))

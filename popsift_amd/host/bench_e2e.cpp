@@ -18,6 +18,7 @@
 #include <popsift/features.h>
 #include <popsift/popsift.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -153,6 +154,12 @@ int main(int argc, char** argv)
     /* warm-up: device buffers and one pinned result block per job that can be in flight (allocating pinned
      * memory takes tens of milliseconds per block and stalls every context while it happens) */
     run(inflight + sift.getContextCount() + 2, warm);
+    /* ... and at least a quarter of a second of work: a GPU that has idled (or run small single-image legs, as before
+     * bench.py's C++ leg) takes that long to bring its clocks back; measured right after, the same run reads half */
+    {
+        const auto w0 = clk::now();
+        for (int k = 0; k < 16 && since(w0) < 0.25; k++) run(std::max(inflight, 32), warm);
+    }
     const auto t0 = clk::now();
     run(images, ct);
     const double sec = since(t0);

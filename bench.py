@@ -466,13 +466,19 @@ def main():
                     out = json.loads(r.stdout.strip().splitlines()[-1])
                     out["devices"], out["jobs_per_submit"] = devs, jobs_per_submit
                     return out
+                # This process has just released ~50 GB of context buffers, and for the next few seconds the kernels of ANOTHER
+                # process run slow (the driver clears released device memory on the GPU): whichever child started first read
+                # low in EVERY pass of popsift-bench (warmup_passes_mpix_s) -- the dense leg 1.08-1.10 Gpix/s where the same
+                # command repeated later reads 2.03-2.08, the sparse leg 8.1 against 9.1 -- while the PCIe link, measured
+                # from here, delivered its 57 GB/s throughout; after a pause of 4 s the first child reads what the later
+                # ones do.  The legs measure the C++ API, not this process's tear-down: wait.
+                time.sleep(5.0)
+                # the keypoint-sparse regime (threshold 0.17, ~2 features per 1000 px: results of a few MB per image, so the
+                # PCIe link is not the limit; a worker takes up to 8 queued jobs per submit, POPSIFT_BATCH)
+                extra["host_to_host_cpp_api_sparse"] = cpp_leg(3, ["--threshold", "0.17", "--images", str(512 * world)], 8)
                 extra["host_to_host_cpp_api"] = cpp_leg(4)
                 # one context per GPU: its download of image i runs under the kernels of image i+1 (fetch_begin / fetch_end)
                 extra["host_to_host_cpp_api_one_context"] = cpp_leg(1)
-                # the keypoint-sparse regime (threshold 0.17, ~2 features per 1000 px): results of a few MB per image,
-                # so the PCIe link is no longer the limit
-                # so the PCIe link is no longer the limit; a worker takes up to 8 queued jobs per submit (POPSIFT_BATCH)
-                extra["host_to_host_cpp_api_sparse"] = cpp_leg(3, ["--threshold", "0.17", "--images", str(512 * world)], 8)
             except Exception as e:  # a reported extra: never fail the bench line over it
                 extra["host_to_host_cpp_api"] = {"error": str(e)[:200]}
         leg("cpp_api")

@@ -153,12 +153,21 @@ int main(int argc, char** argv)
     CallerTime warm, ct;
     /* warm-up: device buffers and one pinned result block per job that can be in flight (allocating pinned
      * memory takes tens of milliseconds per block and stalls every context while it happens) */
-    run(inflight + sift.getContextCount() + 2, warm);
-    /* ... and at least a quarter of a second of work: a GPU that has idled (or run small single-image legs, as before
-     * bench.py's C++ leg) takes that long to bring its clocks back; measured right after, the same run reads half */
+    std::string warm_rates; /* Mpix/s of every warm-up pass: shows a ramp (pools) or a disturbance if there is one */
+    auto        timed_warm = [&](int n) {
+        const auto w1 = clk::now();
+        run(n, warm);
+        char buf[32];
+        snprintf(buf, sizeof(buf), "%s%.0f", warm_rates.empty() ? "" : ", ", (double)n * w * h / since(w1) / 1e6);
+        warm_rates += buf;
+    };
+    timed_warm(inflight + sift.getContextCount() + 2);
+    /* ... and at least a quarter of a second of work at the measured load; the rate of every pass is reported
+     * (warmup_passes_mpix_s): a run disturbed from outside shows there -- bench.py's first child process, started right
+     * after the parent had released ~50 GB of device memory, read half the rate in EVERY pass */
     {
         const auto w0 = clk::now();
-        for (int k = 0; k < 16 && since(w0) < 0.25; k++) run(std::max(inflight, 32), warm);
+        for (int k = 0; k < 16 && since(w0) < 0.25; k++) timed_warm(std::max(inflight, 32));
     }
     const auto t0 = clk::now();
     run(images, ct);
@@ -166,10 +175,10 @@ int main(int argc, char** argv)
     printf("{\"e2e_host_api_mpix_s\": %.1f, \"images\": %d, \"width\": %d, \"height\": %d, \"contexts\": %d, "
            "\"in_flight\": %d, \"callers\": %d, \"ms_per_image\": %.3f, \"features_per_image\": %.0f, "
            "\"descriptors_per_image\": %.0f, \"caller_us_per_image\": {\"enqueue\": %.1f, \"get_blocked\": %.1f, "
-           "\"delete\": %.1f}, \"input\": \"%s\"}\n",
+           "\"delete\": %.1f}, \"warmup_passes_mpix_s\": [%s], \"input\": \"%s\"}\n",
            (double)images * w * h / sec / 1e6, images, w, h, sift.getContextCount(), inflight, callers, sec * 1e3 / images,
            (double)ct.feats / images, (double)ct.descs / images, ct.enqueue * 1e6 / images, ct.get * 1e6 / images,
-           ct.del * 1e6 / images, pgm.empty() ? "built-in generator" : "pgm files");
+           ct.del * 1e6 / images, warm_rates.c_str(), pgm.empty() ? "built-in generator" : "pgm files");
     sift.uninit();
     return 0;
 }

@@ -307,9 +307,12 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
  * walks per pass (4 .. 128, default 128: small values make ordinary patches take the several passes that otherwise only
  * patches of more than 128 rows take -- sigma0 near 2 at the coarsest level; results do not depend on it); PYR_ORDER = 0:
  * level 1 of octave 1 after ALL levels of octave 0 (the default), 1: right behind the level that writes its source
- * plane (results do not depend on it; tools/pyr_order.sh times both). */
+ * plane (results do not depend on it; tools/pyr_order.sh times both); KP_WAVES = waves per image in the launches of
+ * the orientation and descriptor kernels (a multiple of 32; default 8 per wave slot of the device; results do not
+ * depend on it; tools/kp_waves_sweep.sh: 8192 .. 131072 within 1.5 %). */
 enum { POPSIFT_HIP_DEBUG_DET_QCAP = 1, POPSIFT_HIP_DEBUG_CAND_CAP = 2, POPSIFT_HIP_DEBUG_OHIST_CAP = 3,
-       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5, POPSIFT_HIP_DEBUG_PYR_ORDER = 6 };
+       POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5, POPSIFT_HIP_DEBUG_PYR_ORDER = 6,
+       POPSIFT_HIP_DEBUG_KP_WAVES = 7 };
 int popsift_hip_debug_set(popsift_hip_ctx* ctx, int what, int value);
 
 #ifdef __cplusplus

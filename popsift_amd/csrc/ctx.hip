@@ -1571,6 +1571,9 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
     case POPSIFT_HIP_DEBUG_FAIL_ALLOC:
         c->fail_alloc_in = std::max(value, 0);
         return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_KP_WAVES:
+        c->kp_waves = std::min(std::max(value / 32 * 32, 32), 1 << 20);
+        return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_PYR_ORDER:
         c->pyr_order = value;
         return POPSIFT_HIP_OK;

@@ -359,7 +359,11 @@ __global__ __launch_bounds__(64 * KP_NW) void k_orientation(const PyrDesc* __res
         const int   ymax = min(h - 2, (int)roundf(y) + rad);
         const int   wx = xmax - xmin + 1;
         const int   hy = ymax - ymin + 1;
+#ifdef ORI_PROBE_NOLOOP
+        const int   loops = 0;
+#else
         const int   loops = (wx > 0 && hy > 0) ? wx * hy : 0;
+#endif
         /* row of flat index i = floor((i + 0.5) / wx): the half keeps the quotient at least 0.5 / wx away from an integer,
          * far more than the ulp by which v_rcp may miss 1 / wx, so the approximate reciprocal gives the exact row */
         const float inv_wx = __builtin_amdgcn_rcpf((float)max(wx, 1));
@@ -949,7 +953,11 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
              * lies beyond the list's end drops out by itself (above) */
             const int   quarter = ((loops + DESC_GROUPS - 1) / DESC_GROUPS + 2 * DESC_GL - 1) & ~(2 * DESC_GL - 1);
             const int   ibeg = grp * quarter;
+#ifdef DESC_PROBE_NOLOOP
+            const int   iters = 0;
+#else
             const int   iters = quarter / DESC_GL;
+#endif
             /* the lane's place in the row records: LDS address of its current row's record, that row (counted from the top of
              * the PATCH, as a float: it only feeds FMAs), the record and the one of the row below */
             unsigned int rp = rbase32;

@@ -63,6 +63,25 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 }
 
 
+/* The sum over the 64 lanes, in every lane: four DPP adds inside the rows of 16 (quad butterflies, then the two mirrors),
+ * the four row sums through scalar registers.  Register to register -- six __shfl_xor are six dependent ds_bpermute round
+ * trips through the LDS queue (~150 cycles each behind whatever the wave has queued there), three times per descriptor
+ * with the L2 normalisation.  A fixed order of additions like the butterfly's, so results stay reproducible. */
+__device__ __forceinline__ float wave_allsum(float v)
+{
+#define PS_DPP_ADD(CTRL) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false))
+    PS_DPP_ADD(0xB1);  /* quad_perm [1,0,3,2] */
+    PS_DPP_ADD(0x4E);  /* quad_perm [2,3,0,1] */
+    PS_DPP_ADD(0x141); /* row_half_mirror     */
+    PS_DPP_ADD(0x140); /* row_mirror          */
+#undef PS_DPP_ADD
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 /* a value every lane of the wave holds identically, moved to scalar registers */
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -898,8 +917,8 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
              * by ang), which fills only 1/(|cos|+|sin|)^2 = 50..100 % of its bounding box.  Per patch
              * row the square cuts out ONE column interval; the rows' intervals are laid end to end
              * (prefix sum) and the wave walks that flat list, so nearly every lane holds a sample
-             * that passes the exact test below.  Intervals are widened by a pixel: they only have
-             * to be a superset. */
+             * that passes the exact test below.  The intervals only have to be a superset of the
+             * samples inside the square. */
             int T = 0;
             {
                 int         carry = 0;
@@ -925,15 +944,20 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                         } else {
                             ok = ok && (fabsf(b) < 2.5f);
                         }
-                        jlo = max(xmin, (int)floorf(x + lo - 0.01f));
-                        const int jhi = min(xmax, (int)ceilf(x + hi + 0.01f));
+                        /* columns j with lo < j - x < hi: floor(x + lo) + 1 .. ceil(x + hi) - 1, the ends moved out by 1e-3
+                         * pixels -- a hundred times what the reciprocals and products above can be off by (a sample ON the
+                         * edge |u| = 2.5 has weight zero in the cells that exist, so even a miss would be invisible).  Widening
+                         * by a whole pixel on either side, as rounds 1 and 2 did, walked two samples per row for nothing:
+                         * 5 % of the list (k_descriptor 370 -> 352 us, timed loop + 1.4 %). */
+                        jlo = max(xmin, (int)floorf(x + lo - 1e-3f) + 1);
+                        const int jhi = min(xmax, (int)ceilf(x + hi + 1e-3f) - 1);
                         len = ok ? max(jhi - jlo + 1, 0) : 0;
                         if (len == 0) jlo = xmin;
                     }
                     const int incl = wave_incl_scan(len);
                     const int start = carry + incl - len;
                     if (r < hy) rinfo[r] = (unsigned int)start | ((unsigned int)(start - (jlo - xmin)) << 16);
-                    carry += __shfl(incl, 63);
+                    carry += __builtin_amdgcn_readlane(incl, 63);
                 }
                 T = carry;
                 /* Two sentinels close the list: a flat index at or beyond T ends up in "row" hy at column -32767 -- a sample far
@@ -1024,6 +1048,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                 off = (unsigned int)fmaf(fr, pitch4f, fc * 4.0f);
             };
             /* one sample: gradient (gx, gy) at cell-unit position (u, v) -> up to four 64-bit LDS atomics */
+            unsigned int probe_acc = 0u; /* DESC_PROBE_NOATOMIC only */
             auto bin = [&](float u, float v, float gx, float gy) {
                 if (fabsf(u) < 2.5f && fabsf(v) < 2.5f) { /* ISA: control */
                     /* ISA: magnitude + angle */
@@ -1062,13 +1087,21 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
 /* round(w * wgt) for both halves of the word by the float trick: w * wgt + 2^23 holds the integer in its mantissa (the
  * products stay below 2^23: make_desc_rec keeps fbits <= 14), one v_and strips the exponent -- an FMA and an AND, both
  * full rate, where v_cvt_u32_f32 runs at half rate */
+/* timing probes (results invalid): DESC_PROBE_NOATOMIC folds the words into a register instead of adding them to the LDS
+ * histogram, DESC_PROBE_NOLOAD takes the taps from registers instead of memory (tools/build_variants.py) */
+#ifdef DESC_PROBE_NOATOMIC
+#define PS_CELL_ADD(ADDR, LO, HI) probe_acc ^= (LO) ^ (HI) ^ (ADDR);
+#else
+#define PS_CELL_ADD(ADDR, LO, HI)                                                                             \
+    __hip_atomic_fetch_add((lds_fix64*)(size_t)(ADDR), ((fix64)(HI) << 32) | (fix64)(LO), __ATOMIC_RELAXED,    \
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 #define PS_CELL(ADDR, WGT)                                                                                     \
     {                                                                                                          \
         const float        wgt = (WGT);                                                                        \
         const unsigned int lo = __float_as_uint(fmaf(w0, wgt, 8388608.0f)) & 0x7fffffu;                        \
         const unsigned int hi = __float_as_uint(fmaf(do0, wgt, 8388608.0f)) & 0x7fffffu;                       \
-        __hip_atomic_fetch_add((lds_fix64*)(size_t)(ADDR), ((fix64)hi << 32) | (fix64)lo, __ATOMIC_RELAXED,    \
-                               __HIP_MEMORY_SCOPE_WORKGROUP);                                                  \
+        PS_CELL_ADD(ADDR, lo, hi)                                                                              \
     }
                     if (y0) {
                         if (x0) PS_CELL(e0, wy0 * wx0)
@@ -1079,6 +1112,7 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                         if (x1) PS_CELL(e1 + DESC_RS * 8u + 64u, wy1 * fx)
                     }
 #undef PS_CELL
+#undef PS_CELL_ADD
                 }
             };
             /* ISA: control */
@@ -1088,18 +1122,24 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
             float u_a = 3.0f, v_a = 3.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
             float u_b = 3.0f, v_b = 3.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
             const Taps taps(corner, pitch);
+#ifdef DESC_PROBE_NOLOAD
+#define PS_TAPS(OFF, A0, A1, A2, A3) { A0 = __uint_as_float(OFF) * 1e-9f; A1 = u0; A2 = v0; A3 = __uint_as_float((OFF) ^ 0x3f800000u); }
+#else
+#define PS_TAPS(OFF, A0, A1, A2, A3) taps.load_b(OFF, A0, A1, A2, A3);
+#endif
             if (loops > 0) {
                 coord(ibeg + sub, off_a, u_a, v_a);
-                taps.load_b(off_a, a0, a1, a2, a3);
+                PS_TAPS(off_a, a0, a1, a2, a3)
             }
             for (int t = 0, i = ibeg + sub; t < iters; t += 2, i += 2 * DESC_GL) {
                 coord(i + DESC_GL, off_b, u_b, v_b);
-                taps.load_b(off_b, b0, b1, b2, b3);
+                PS_TAPS(off_b, b0, b1, b2, b3)
                 bin(u_a, v_a, a0 - a1, a2 - a3);
                 coord(i + 2 * DESC_GL, off_a, u_a, v_a);
-                taps.load_b(off_a, a0, a1, a2, a3);
+                PS_TAPS(off_a, a0, a1, a2, a3)
                 bin(u_b, v_b, b0 - b1, b2 - b3);
             }
+            if (probe_acc == 0x12345u) desc[(size_t)d * 128 + lane] = 1.0f; /* never true: keeps the probe's arithmetic alive */
             wave_lds_sync(); /* ISA: end */
             } /* passes */
         }
@@ -1125,20 +1165,17 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
         /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            sum = wave_allsum(sum);
             v0 = scalbnf(sqrtf(v0 / sum), sc.norm_multi);
             v1 = scalbnf(sqrtf(v1 / sum), sc.norm_multi);
         } else {
             float sq = v0 * v0 + v1 * v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            sq = wave_allsum(sq);
             const float norm = sqrtf(sq);
             v0 = fminf(v0, 0.2f * norm);
             v1 = fminf(v1, 0.2f * norm);
             sq = v0 * v0 + v1 * v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            sq = wave_allsum(sq);
             float rn = 1.0f / sqrtf(sq);
             rn = scalbnf(rn, sc.norm_multi);
             v0 = v0 * rn;
@@ -1247,9 +1284,7 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
                 }
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    float v = acc[b];
-#pragma unroll
-                    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+                    const float v = wave_allsum(acc[b]);
                     if (lane == 0) feat[(cell << 3) + b] = v;
                 }
             }
@@ -1260,20 +1295,17 @@ __global__ __launch_bounds__(256) void k_descriptor_grid(const PyrDesc* __restri
         float v0 = feat[lane], v1 = feat[lane + 64];
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            sum = wave_allsum(sum);
             v0 = scalbnf(sqrtf(v0 / sum), sc.norm_multi);
             v1 = scalbnf(sqrtf(v1 / sum), sc.norm_multi);
         } else {
             float sq = v0 * v0 + v1 * v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            sq = wave_allsum(sq);
             const float norm = sqrtf(sq);
             v0 = fminf(v0, 0.2f * norm);
             v1 = fminf(v1, 0.2f * norm);
             sq = v0 * v0 + v1 * v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            sq = wave_allsum(sq);
             float rn = 1.0f / sqrtf(sq);
             rn = scalbnf(rn, sc.norm_multi);
             v0 = v0 * rn;
@@ -1454,20 +1486,17 @@ __global__ __launch_bounds__(256) void k_descriptor_notile(const PyrDesc* __rest
         /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave */
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            sum = wave_allsum(sum);
             v0 = scalbnf(sqrtf(v0 / sum), sc.norm_multi);
             v1 = scalbnf(sqrtf(v1 / sum), sc.norm_multi);
         } else {
             float sq = v0 * v0 + v1 * v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            sq = wave_allsum(sq);
             const float norm = sqrtf(sq);
             v0 = fminf(v0, 0.2f * norm);
             v1 = fminf(v1, 0.2f * norm);
             sq = v0 * v0 + v1 * v1;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+            sq = wave_allsum(sq);
             float rn = 1.0f / sqrtf(sq);
             rn = scalbnf(rn, sc.norm_multi);
             v0 = v0 * rn;

@@ -93,3 +93,38 @@ def test_batch_argument_errors(gpu_hip):
     assert _same(_canon(*pend.result()), _canon(f0, d0))
     assert _same(_canon(*ctx.fetch_item(2)), _canon(f0, d0))
     ctx.close()
+
+
+def test_a_failed_allocation_inside_a_batch_is_recoverable(gpu_hip):
+    """A batch grows the buffers of every slot it uses; when the n-th device allocation fails (DEBUG_FAIL_ALLOC) the
+    submit returns ERR_OOM, and the context -- some slots sized, some not, some buffers freed -- must take the next
+    batch as if nothing had happened: same results as single submits, for a failure at any of the first allocations of
+    the second, third and fourth slot."""
+    small = [synth(430 + k, 160, 120) for k in range(2)]
+    big = [synth(440 + k, 400, 300) for k in range(4)]
+    single = gpu_hip.Context()
+    want_small = [_canon(*single.submit(im).fetch()) for im in small]
+    want_big = [_canon(*single.submit(im).fetch()) for im in big]
+    single.close()
+    failures = 0
+    for nth in (1, 2, 5, 9, 14, 17, 23, 30, 38):
+        ctx = gpu_hip.Context()
+        ctx.submit_batch(small)                       # two slots sized for the small images
+        for k in range(2):
+            assert _same(_canon(*ctx.fetch_item(k)), want_small[k])
+        ctx.debug_set(gpu_hip.DEBUG_FAIL_ALLOC, nth)  # four slots, bigger planes: every slot allocates
+        try:
+            ctx.submit_batch(big)
+        except gpu_hip.PopsiftHipError as e:
+            assert e.status == gpu_hip.ERR_OOM
+            failures += 1
+        ctx.debug_set(gpu_hip.DEBUG_FAIL_ALLOC, 0)
+        ctx.submit_batch(big)
+        assert len(ctx.wait_batch()) == 4
+        for k in range(4):
+            assert _same(_canon(*ctx.fetch_item(k)), want_big[k]), (nth, k)
+        ctx.submit_batch(small)
+        for k in range(2):
+            assert _same(_canon(*ctx.fetch_item(k)), want_small[k]), (nth, k)
+        ctx.close()
+    assert failures >= 5      # most of the chosen allocations exist (the later ones depend on the slots' buffer count)

@@ -57,7 +57,7 @@ def check_case(O, hip, kw, img, threads=16):
                 n = max(st["n_desc"], 1)
                 # the bars of the named cases (util.descriptor_parity)
                 grid = kw["desc_mode"] == 2
-                pok, pmsg = descriptor_parity(st, grid_mode=grid, thin_grid=grid and min(img.shape) <= 48)
+                pok, pmsg = descriptor_parity(st, grid_mode=grid, min_dim=min(ctx.octave_dims(0)))
                 dok = st["missing"] == 0 and st["max_sigma_rel"] < 1e-5 and pok
                 ok = ok and dok
                 msg = pmsg if not dok else "desc_bad %d/%d max %.1e" % (st["desc_bad"], n, st["max_desc"])

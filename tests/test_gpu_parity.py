@@ -54,7 +54,7 @@ CASES = [
     # 173 rows -- more than one pass of k_descriptor's row table)
     ("sigma2_levels2_large_patches", dict(levels=2, sigma=2.0), (44, 320, 240)),
     # grid descriptor on an image so thin that every keypoint sits at the clamped border (the one kind of case the
-    # open-ended fuzz runs flag): own bar, util.descriptor_parity(thin_grid=True)
+    # open-ended fuzz runs flag): own bar, util.descriptor_parity(min_dim <= 96: the octave-0 plane is 600 x 48)
     ("grid_descriptor_thin_300x24", dict(desc_mode=2), (45, 300, 24)),
 ]
 
@@ -77,7 +77,7 @@ def assert_planes_equal(orc, ctx, levels):
                     o, kind, l, int((bits(a) != bits(b)).sum()), float(np.abs(a - b).max()))
 
 
-def assert_keypoints_match(orc, ctx, grid_mode=False, thin_grid=False):
+def assert_keypoints_match(orc, ctx, grid_mode=False):
     eo, eh = orc.extrema(), ctx.extrema()
     key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
     assert key(eo) == key(eh)                       # same set, bit-exact positions
@@ -90,7 +90,7 @@ def assert_keypoints_match(orc, ctx, grid_mode=False, thin_grid=False):
     n = max(st["n_desc"], 1)
     assert st["num_ori_diff"] <= max(1, st["n_a"] // 2000)
     assert st["ang_bad"] <= max(2, n // 2000), st
-    ok, msg = descriptor_parity(st, grid_mode=grid_mode, thin_grid=thin_grid)
+    ok, msg = descriptor_parity(st, grid_mode=grid_mode, min_dim=min(ctx.octave_dims(0)))
     assert ok, msg
     # layout contract of the reference: descriptors feature by feature, octaves ascending
     idx = np.concatenate([f["desc_idx"][: int(f["num_ori"])] for f in fh]) if len(fh) else np.zeros(0, int)
@@ -105,7 +105,7 @@ def test_hip_matches_oracle(oracle_mod, gpu_hip, name, kw, spec):
     orc, ctx = run_both(oracle_mod, gpu_hip, kw, img)
     assert_planes_equal(orc, ctx, max(2, kw.get("levels", 3)))
     grid = kw.get("desc_mode", 0) == 2
-    assert_keypoints_match(orc, ctx, grid_mode=grid, thin_grid=grid and min(img.shape) <= 48)
+    assert_keypoints_match(orc, ctx, grid_mode=grid)
     ctx.close()
 
 

@@ -57,6 +57,8 @@ def parse():
                     help="run only the single-context passes (the command the profiles/ *_single_image* files were taken with)")
     ap.add_argument("--cpu-images", type=int, default=6, help="images timed for the CPU baseline")
     ap.add_argument("--debug", default="", help="tuning runs: popsift_hip_debug_set switches, what:value,...")
+    ap.add_argument("--size", default=None, help="tuning runs (--quick): WxH of the synthetic images instead of 1920x1080 "
+                                                 "(3840x2160: BASELINE.json config 3)")
     ap.add_argument("--threshold", type=float, default=None,
                     help="tuning runs (--quick): Config threshold of the timed loop (0.17: the keypoint-sparse regime)")
     return ap.parse_args()
@@ -203,7 +205,12 @@ def single_image(ctx, ptr, hip, n=5):
 
 
 def main():
+    global W, H
     args = parse()
+    if args.size:
+        if not args.quick:
+            raise SystemExit("bench.py: --size is for --quick tuning runs; the bench line is BASELINE.json's 1920x1080")
+        W, H = (int(v) for v in args.size.lower().split("x"))
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     legs = {}

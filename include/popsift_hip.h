@@ -309,10 +309,14 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
  * level 1 of octave 1 after ALL levels of octave 0 (the default), 1: right behind the level that writes its source
  * plane (results do not depend on it; tools/pyr_order.sh times both); KP_WAVES = waves per image in the launches of
  * the orientation and descriptor kernels (a multiple of 32; default 8 per wave slot of the device; results do not
- * depend on it; tools/kp_waves_sweep.sh: 8192 .. 131072 within 1.5 %). */
+ * depend on it; tools/kp_waves_sweep.sh: 8192 .. 131072 within 1.5 %); BLUR_PATH = which kernels build the pyramid's
+ * plane-to-plane levels: 0 by plane size (default), 1 the one-tile-per-workgroup kernels only, 2 the strip-march kernels
+ * wherever they apply, also on small planes (results do not depend on it: every path is bit-identical; the tests run
+ * their small images through 2); BLUR_SEG = rows per segment of the march kernels (a multiple of 32; 0 = chosen from the
+ * plane and the batch). */
 enum { POPSIFT_HIP_DEBUG_DET_QCAP = 1, POPSIFT_HIP_DEBUG_CAND_CAP = 2, POPSIFT_HIP_DEBUG_OHIST_CAP = 3,
        POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5, POPSIFT_HIP_DEBUG_PYR_ORDER = 6,
-       POPSIFT_HIP_DEBUG_KP_WAVES = 7 };
+       POPSIFT_HIP_DEBUG_KP_WAVES = 7, POPSIFT_HIP_DEBUG_BLUR_PATH = 8, POPSIFT_HIP_DEBUG_BLUR_SEG = 9 };
 int popsift_hip_debug_set(popsift_hip_ctx* ctx, int what, int value);
 
 #ifdef __cplusplus

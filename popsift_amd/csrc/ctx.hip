@@ -113,6 +113,7 @@ struct popsift_hip_ctx {
     int       det_qcap = 1 << 30;  /* popsift_hip_debug_set hooks, see popsift_hip.h */
     int       desc_rows = 1 << 30;
     int       pyr_order = 0;
+    BlurTune  blur_tune{0, 0}; /* BLUR_PATH / BLUR_SEG debug switches */
     int       cand_cap_init = 1 << 20;
     bool      cand_cap_user = false;
     int       ohist_cap_init = 0;
@@ -507,10 +508,10 @@ int blur_launch(popsift_hip_ctx* c, const BlurArgs& a, int mode, int span, int t
          * brackets PROFILE_REPS back-to-back launches with one event pair: the event-to-kernel gap
          * (~4 us, as large as a small launch itself) is amortised instead of being billed per launch. */
         HIP_TRY(c, hipEventRecord(ep.a, c->stream));
-        for (int rep = 0; rep < PROFILE_REPS; rep++) HIP_TRY(c, launch_blur(a, c->bd, c->nb, mode, span, tile_h, c->stream));
+        for (int rep = 0; rep < PROFILE_REPS; rep++) HIP_TRY(c, launch_blur(a, c->bd, c->nb, mode, span, tile_h, c->stream, c->blur_tune));
         HIP_TRY(c, hipEventRecord(ep.b, c->stream));
     } else {
-        HIP_TRY(c, launch_blur(a, c->bd, c->nb, mode, span, tile_h, c->stream));
+        HIP_TRY(c, launch_blur(a, c->bd, c->nb, mode, span, tile_h, c->stream, c->blur_tune));
         SYNC_CHK(c, "k_blur_tile");
     }
     return 0;
@@ -1576,6 +1577,13 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_PYR_ORDER:
         c->pyr_order = value;
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_BLUR_PATH:
+        if (value < 0 || value > 2) return fail(c, POPSIFT_HIP_ERR_INVALID, "BLUR_PATH: 0, 1 or 2");
+        c->blur_tune.path = value;
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_BLUR_SEG:
+        c->blur_tune.seg_rows = std::max(value, 0);
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_DESC_ROWS:
         c->desc_rows = c->sc.desc_rows = std::max(value, 4);

@@ -32,11 +32,24 @@ struct BlurArgs {
     /* level 0 only (the first launch of an image): words of the slot's Counters this launch clears, so that the image needs
      * no separate fill launch before detection; 0 otherwise */
     int     zero_words;
+    /* march kernels (blur_march.hip) only: rows per segment, a multiple of 32; tiles_y = segments per strip */
+    int     seg_rows;
+};
+
+/* how launch_blur picks the kernel of a plane-to-plane level launch (popsift_hip_debug_set BLUR_PATH / BLUR_SEG) */
+struct BlurTune {
+    int path;     /* 0: by plane size, 1: tile kernels only (pyramid.hip), 2: march kernels wherever they apply */
+    int seg_rows; /* 0: chosen from the plane and the batch, else rows per segment (rounded to a multiple of 32) */
 };
 
 int        blur_tile_w();
 int        blur_tile_h(int w, int h); /* 32 or 64 rows, by plane size */
-hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode, int span, int tile_h, hipStream_t s);
+hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode, int span, int tile_h, hipStream_t s,
+                       BlurTune tune = BlurTune{0, 0});
+/* blur_march.hip: level l >= 1 of a large plane, strips of 128 columns marched down 32 rows a step */
+bool       blur_march_supported(const BlurArgs& a, int halo);
+int        blur_march_seg_rows(int w, int h, int nb, int want_wgs);
+hipError_t launch_blur_march(BlurArgs a, const BatchDesc& bd, int nb, int halo, int seg_rows, hipStream_t s);
 /* two plane-to-plane level launches with 32-row tiles in one (small octaves) */
 hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, const BatchDesc& bd, int nb, hipStream_t s);
 

@@ -24,14 +24,13 @@
 
 #include "sift_types.h"
 #include "kernels.h"
+#include "blur_common.h"
 
 namespace popsift_hip {
 
 namespace {
 
-constexpr int TW = 128; /* tile width  (outputs) */
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+constexpr int TW = BLUR_TW; /* tile width  (outputs) */
 
 /* One axis of a CUDA linear-filter fetch at normalised coordinate r
  * (s_image.cu:140-169: normalised coords, clamp, linear, 1.8 fixed-point weight). */
@@ -61,17 +60,6 @@ __device__ __forceinline__ float texel<float>(const float* img, int w, int h, in
     y = clampi(y, 0, h - 1);
     return img[(size_t)y * pitch + x];
 }
-
-/* XCD-aware tile order: blocks b and b+8 share an XCD (and its 4 MiB L2), so
- * give each XCD a contiguous run of tiles -- neighbouring tiles share halos. */
-__device__ __forceinline__ int xcd_remap(int b, int n)
-{
-    const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 /*
  * MODE 0: level l >= 1 from plane l-1 (centre tap first in the H pass, DoG out)
@@ -612,6 +600,10 @@ int blur_tile_h(int w, int h)
     return tiles64 >= min_tiles ? 64 : 32;
 }
 
+/* march kernels from this many pixels per launch (all images of the batch) on, cut into at least this many workgroups */
+constexpr long BLUR_MARCH_MIN_PX = 1500000;
+constexpr int  BLUR_MARCH_WGS = 768;
+
 /* lanes per 4x4 block for small planes: 1 / 2 / 4 -> pyramid stage of a 1080p image 291 / 295 / 275 us */
 constexpr int BLUR_SMALL_LP = 4;
 /* planes whose level launch -- for all nb images of the batch -- is one round of workgroups (at most one 128 x 32 tile per
@@ -675,10 +667,19 @@ static hipError_t launch_blur_small(const BlurArgs& a, const BatchDesc& bd, int 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode, int span, int tile_h, hipStream_t s)
+hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode, int span, int tile_h, hipStream_t s, BlurTune tune)
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
+    /* large planes: the march kernel (blur_march.hip).  "Large" = the launch fills the device with workgroups that make at
+     * least two steps each; below that a level launch is a latency chain and the one-tile-per-workgroup kernels are shorter */
+    if (mode == 0 && tune.path != 1 && blur_march_supported(a, halo)) {
+        const long px = (long)a.w * a.h * nb;
+        if (tune.path == 2 || px >= BLUR_MARCH_MIN_PX) {
+            int seg = tune.seg_rows > 0 ? std::max(32, tune.seg_rows / 32 * 32) : blur_march_seg_rows(a.w, a.h, nb, BLUR_MARCH_WGS);
+            return launch_blur_march(a, bd, nb, halo, seg, s);
+        }
+    }
     if (mode == 0 && tile_h == 32 && a.dog_off < 0 && halo <= 16 && blur_is_small(a.w, a.h, nb)) return launch_blur_small(a, bd, nb, halo, s);
     /* the 27-tap level of a large plane: 512 lanes, two per 4x4 block -- every lane filters half the rows of the
      * throughput shape and the tile keeps its LDS footprint (24.9 instead of 27.1 us per 3840 x 2160 launch; 1024 lanes

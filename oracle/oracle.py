@@ -105,6 +105,8 @@ def lib():
         L.oracle_fetch.argtypes = [vp, vp, vp]
         L.oracle_fetch_extrema.argtypes = [vp, vp]
         L.oracle_fetch_raw_desc.argtypes = [vp, vp]
+        L.oracle_redo_descriptors.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+        L.oracle_warp32_sort64.argtypes = [vp, vp]
         L.oracle_solve3.argtypes = [vp, vp]
         L.oracle_normalize.argtypes = [vp, C.c_int, C.c_int]
         L.oracle_match.restype = None
@@ -201,6 +203,24 @@ class Oracle:
         lib().oracle_fetch(self._h, feats.ctypes.data, desc.ctypes.data)
         return feats, desc
 
+    def redo_descriptors(self, orientations=None, ulps=0, sigma=None, sigma_ulps=0):
+        """Test hook: all descriptors again in the frames of `orientations` ((n_features, 4) float32 in fetch order; None =
+        the oracle's own) and scales `sigma` ((n_features,) float32 in OCTAVE units; None = own), moved by `ulps` /
+        `sigma_ulps` units in the last place."""
+        nf = self.counts()[0]
+        optr = sptr = None
+        if orientations is not None:
+            orientations = np.ascontiguousarray(orientations, np.float32)
+            assert orientations.shape == (nf, 4)
+            optr = orientations.ctypes.data
+        if sigma is not None:
+            sigma = np.ascontiguousarray(sigma, np.float32)
+            assert sigma.shape == (nf,)
+            sptr = sigma.ctypes.data
+        if lib().oracle_redo_descriptors(self._h, optr, int(ulps), sptr, int(sigma_ulps)):
+            raise RuntimeError("redo_descriptors")
+        return self
+
     def raw_descriptors(self):
         _, nd = self.counts()
         desc = np.zeros((nd, 128), np.float32)
@@ -212,6 +232,15 @@ class Oracle:
         out = np.zeros(nf, EXTREMUM_DTYPE)
         lib().oracle_fetch_extrema(self._h, out.ctypes.data)
         return out
+
+
+def warp32_sort64(yval):
+    """Warp32<float>::sort64 on 64 values: the indices held by x of lanes 0..31, then y of lanes 0..31."""
+    y = np.ascontiguousarray(yval, np.float32)
+    assert y.shape == (64,)
+    out = np.zeros(64, np.int32)
+    lib().oracle_warp32_sort64(y.ctypes.data, out.ctypes.data)
+    return out
 
 
 def solve3(A, b):

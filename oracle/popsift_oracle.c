@@ -756,6 +756,60 @@ static inline void get_gradiant(float* grad, float* theta, int x, int y, const f
 }
 
 /* s_orientation.cu:60-242 ori_par */
+/* Warp32::shiftit (warp_bitonic_sort.h:58-70) for all 32 lanes at once: every lane reads its partner's value and index
+ * as they were BEFORE the step (the shuffles of a warp execute together) */
+static void warp32_shiftit(const float* arr, int* idx, int shift, int direction, int increasing)
+{
+    int nxt[32];
+    for (int t = 0; t < 32; t++) {
+        const int   o = t ^ (1 << shift);
+        const float my_val = arr[idx[t]];
+        const float other_val = arr[idx[o]];
+        const int   reverse = (t & (1 << direction)) != 0;
+        const int   id_less = (t & (1 << shift)) == 0;
+        const int   my_more = id_less ? (my_val > other_val) : (my_val < other_val);
+        const int   must_swap = !(my_more ^ reverse ^ increasing);
+        nxt[t] = must_swap ? idx[o] : idx[t];
+    }
+    for (int t = 0; t < 32; t++) idx[t] = nxt[t];
+}
+
+/* Warp32::sort64 (warp_bitonic_sort.h:35-56): x[t], y[t] = the int2 of lane t */
+static void warp32_sort64(const float* arr, int* x, int* y)
+{
+    for (int outer = 0; outer < 5; outer++)
+        for (int inner = outer; inner >= 0; inner--) {
+            warp32_shiftit(arr, x, inner, outer + 1, 0);
+            warp32_shiftit(arr, y, inner, outer + 1, 1);
+        }
+    for (int t = 0; t < 32; t++)
+        if (arr[x[t]] < arr[y[t]]) {
+            const int m = y[t];
+            y[t] = x[t];
+            x[t] = m;
+        }
+    for (int outer = 0; outer < 5; outer++)
+        for (int inner = outer; inner >= 0; inner--) {
+            warp32_shiftit(arr, x, inner, outer + 1, 0);
+            warp32_shiftit(arr, y, inner, outer + 1, 0);
+        }
+}
+
+/* unit-test entry: the 64 indices after sort64 (x of lanes 0 .. 31, then y of lanes 0 .. 31) */
+void oracle_warp32_sort64(const float* yval64, int* out64)
+{
+    int x[32], y[32];
+    for (int t = 0; t < 32; t++) {
+        x[t] = t;
+        y[t] = t + 32;
+    }
+    warp32_sort64(yval64, x, y);
+    for (int t = 0; t < 32; t++) {
+        out64[t] = x[t];
+        out64[32 + t] = y[t];
+    }
+}
+
 static void orientation_one(const oracle_ctx* c, ext_t* e)
 {
     const oct_t* oc = &c->oct[e->octave];
@@ -825,19 +879,15 @@ static void orientation_one(const oracle_ctx* c, ext_t* e)
         yval[bin] = predicate ? -(num * num) / (4.0f * denB) + sm_hist[prev] : -INFINITY;
     }
 
-    /* bitonic sort64 descending (warp_bitonic_sort.h:35-55): pick the 4 largest;
-     * ties resolved towards the lower bin */
-    int best[4];
-    int used[64] = {0};
-    for (int k = 0; k < 4; k++) {
-        int bi = -1;
-        for (int b = 0; b < 64; b++) {
-            if (used[b]) continue;
-            if (bi < 0 || yval[b] > yval[bi]) bi = b;
-        }
-        used[bi] = 1;
-        best[k] = bi;
+    /* BitonicSort::Warp32<float>::sort64 (warp_bitonic_sort.h:35-78), restated literally: lane t of 32 ends with
+     * best_index.x = the index of the t-th largest yval; threads 0 .. 3 use theirs (s_orientation.cu:207-231) */
+    int bx[32], by[32];
+    for (int t = 0; t < 32; t++) {
+        bx[t] = t;
+        by[t] = t + 32;
     }
+    warp32_sort64(yval, bx, by);
+    const int* best = bx;
     const float yval_ref = 0.8f * yval[best[0]];
     int         angles = 0;
     for (int k = 0; k < 4; k++) {
@@ -1486,6 +1536,31 @@ void oracle_match(const float* l, int l_len, const float* r, int r_len, popsift_
 
 /* ------------------------------------------------------------------ driver */
 
+static void all_descriptors(oracle_ctx* c)
+{
+    const int n = c->ext_total;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(c->threads) if (c->threads > 1)
+    for (int i = 0; i < n; i++) {
+        const ext_t* e = &c->ext[i];
+        for (int k = 0; k < e->num_ori; k++) {
+            float* raw = c->desc_raw + 128 * (size_t)(e->idx_ori + k);
+            float* out = c->desc + 128 * (size_t)(e->idx_ori + k);
+            if (c->p.desc_mode == POPSIFT_HIP_DESC_GRID)
+                descriptor_grid_one(c, e, e->orientation[k], raw);
+            else if (c->p.desc_mode == POPSIFT_HIP_DESC_IGRID)
+                descriptor_igrid_one(c, e, e->orientation[k], raw);
+            else if (c->p.desc_mode == POPSIFT_HIP_DESC_ILOOP)
+                descriptor_iloop_one(c, e, e->orientation[k], raw);
+            else if (c->p.desc_mode == POPSIFT_HIP_DESC_NOTILE)
+                descriptor_notile_one(c, e, e->orientation[k], raw);
+            else
+                descriptor_one(c, e, e->orientation[k], raw);
+            memcpy(out, raw, 128 * sizeof(float));
+            oracle_normalize(out, c->p.norm_mode, c->norm_multi);
+        }
+    }
+}
+
 static int keypoint_stages(oracle_ctx* c)
 {
     if (c->n_oct <= 0) return -1;
@@ -1510,26 +1585,30 @@ static int keypoint_stages(oracle_ctx* c)
         c->desc_raw = (float*)malloc(sizeof(float) * 128 * (size_t)c->desc_cap);
         if (!c->desc || !c->desc_raw) return -1;
     }
-#pragma omp parallel for schedule(dynamic, 16) num_threads(c->threads) if (c->threads > 1)
-    for (int i = 0; i < n; i++) {
-        const ext_t* e = &c->ext[i];
-        for (int k = 0; k < e->num_ori; k++) {
-            float* raw = c->desc_raw + 128 * (size_t)(e->idx_ori + k);
-            float* out = c->desc + 128 * (size_t)(e->idx_ori + k);
-            if (c->p.desc_mode == POPSIFT_HIP_DESC_GRID)
-                descriptor_grid_one(c, e, e->orientation[k], raw);
-            else if (c->p.desc_mode == POPSIFT_HIP_DESC_IGRID)
-                descriptor_igrid_one(c, e, e->orientation[k], raw);
-            else if (c->p.desc_mode == POPSIFT_HIP_DESC_ILOOP)
-                descriptor_iloop_one(c, e, e->orientation[k], raw);
-            else if (c->p.desc_mode == POPSIFT_HIP_DESC_NOTILE)
-                descriptor_notile_one(c, e, e->orientation[k], raw);
-            else
-                descriptor_one(c, e, e->orientation[k], raw);
-            memcpy(out, raw, 128 * sizeof(float));
-            oracle_normalize(out, c->p.norm_mode, c->norm_multi);
+    all_descriptors(c);
+    return 0;
+}
+
+/* Test hook: the descriptors again, in OTHER frames -- orientations `ori` (4 floats per extremum, in the order of
+ * oracle_fetch; NULL: the oracle's own) moved by `ori_ulps` units in the last place, scales `sigma` (one float per extremum,
+ * in OCTAVE units like ext_t::sigma; NULL: the oracle's own) moved by `sigma_ulps`.  Extrema, their number of
+ * orientations and the order of the descriptors stay as they are.  tests/ use it to take orientation and scale out of a
+ * descriptor comparison (the HIP path's values go in: its angles differ from the oracle's in the last bits like two runs
+ * of the reference do, its sigma by the device's powf) and to measure how far an ulp of either moves a descriptor. */
+int oracle_redo_descriptors(oracle_ctx* c, const float* ori, int ori_ulps, const float* sigma, int sigma_ulps)
+{
+    if (!c || c->n_oct <= 0 || !c->desc) return -1;
+    for (int i = 0; i < c->ext_total; i++) {
+        for (int k = 0; k < c->ext[i].num_ori; k++) {
+            float a = ori ? ori[4 * (size_t)i + k] : c->ext[i].orientation[k];
+            for (int u = 0; u < (ori_ulps < 0 ? -ori_ulps : ori_ulps); u++) a = nextafterf(a, ori_ulps < 0 ? -INFINITY : INFINITY);
+            c->ext[i].orientation[k] = a;
         }
+        float sg = sigma ? sigma[i] : c->ext[i].sigma;
+        for (int u = 0; u < (sigma_ulps < 0 ? -sigma_ulps : sigma_ulps); u++) sg = nextafterf(sg, sigma_ulps < 0 ? -INFINITY : INFINITY);
+        c->ext[i].sigma = sg;
     }
+    all_descriptors(c);
     return 0;
 }
 

@@ -53,7 +53,13 @@ int oracle_fetch_extrema(const oracle_ctx* c, popsift_hip_extremum* out);
 /* un-normalised 128-bin histograms, same order as the descriptors */
 int oracle_fetch_raw_desc(const oracle_ctx* c, float* desc);
 
+/* test hook: recompute all descriptors in the frames of the orientations `ori` (4 per extremum, order of oracle_fetch;
+ * NULL = the oracle's own) and scales `sigma` (1 per extremum, octave units; NULL = own), moved by so many units in the
+ * last place */
+int oracle_redo_descriptors(oracle_ctx* c, const float* ori, int ori_ulps, const float* sigma, int sigma_ulps);
+
 /* isolated helpers for unit tests */
+void  oracle_warp32_sort64(const float* yval64, int* out64);  /* common/warp_bitonic_sort.h:35-78, all 64 indices */
 int   oracle_solve3(float A[9], float b[3]);                 /* s_solve.h:24-85 */
 void  oracle_normalize(float* d128, int norm_mode, int norm_multi); /* s_desc_norm_*.h */
 /* brute-force 2-NN of every left descriptor among the right ones (features.cu:157-221) */

@@ -103,6 +103,7 @@ struct popsift_hip_ctx {
     int  in_w = 0, in_h = 0;
     int  frozen_octaves = -1;
     bool have_image = false, finished = false;
+    bool batch_ok = false; /* the last submit enqueued everything it had to: there are (or will be) results to wait for */
     int  nb = 1; /* images of the submitted batch */
 
     /* one slot per image of a batch; a plain submit uses slot 0 */
@@ -672,6 +673,11 @@ int submit_common(popsift_hip_ctx* c, const void* const* imgs, int nb, int kind,
         /* one batch in flight per context: drain the previous one */
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    /* from here until every enqueue below has succeeded the context holds NO results: a submit that fails half-way (an
+     * allocation for a new slot of a larger batch of the same size, a pinned staging buffer, a launch) must not leave
+     * wait / fetch with the previous batch's counts for slots whose kernels never ran */
+    c->batch_ok = false;
+    c->finished = false;
     if (int rc = prepare_geometry(c, w, h, nb)) return rc;
     c->nb = nb;
     refresh_caps(c);
@@ -723,6 +729,7 @@ int submit_common(popsift_hip_ctx* c, const void* const* imgs, int nb, int kind,
     HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
     c->have_image = true;
     c->finished = false;
+    c->batch_ok = true;
     c->submit_seq++;
     for (ImageSlot& sl : c->slot) sl.moved = false;
     return 0;
@@ -730,11 +737,11 @@ int submit_common(popsift_hip_ctx* c, const void* const* imgs, int nb, int kind,
 
 int finish(popsift_hip_ctx* c)
 {
-    if (!c->have_image) return fail(c, POPSIFT_HIP_ERR_STATE, "no image submitted");
+    if (!c->have_image || !c->batch_ok) return fail(c, POPSIFT_HIP_ERR_STATE, c->have_image ? "the last submit failed" : "no image submitted");
     if (c->finished) return 0;
     POPSIFT_RANGE("popsift_hip: wait");
     HIP_TRY(c, hipSetDevice(c->device));
-    bool rerun = false;
+    bool rerun = false, fits = false;
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         /* the largest need over the images of the batch */
@@ -751,7 +758,10 @@ int finish(popsift_hip_ctx* c)
         const bool desc_short = ori_max > c->desc_cap;
         const bool cand_short = qmax > c->cand_cap / DET_SUBQ;
         const bool hist_short = (size_t)ext_max > c->ohist_cap;
-        if (!desc_short && !cand_short && !hist_short) break;
+        if (!desc_short && !cand_short && !hist_short) {
+            fits = true;
+            break;
+        }
         /* more candidates / descriptors than the buffers hold (the reference reallocates between
          * stages, sift_pyramid.cu:179-209): grow and redo the keypoint stages of this batch */
         if (desc_short)
@@ -764,6 +774,9 @@ int finish(popsift_hip_ctx* c)
         HIP_TRY(c, hipEventRecord(c->ev_end, c->stream));
         rerun = true;
     }
+    /* every re-run sizes the buffers from the counts of the run before, so the second attempt fits unless the counts
+     * themselves were clipped; eight rounds of growing without fitting is a defect, not a result to hand out clipped */
+    if (!fits) return fail(c, POPSIFT_HIP_ERR_DEVICE, "the keypoint buffers still do not fit after 8 grow-and-rerun rounds");
     popsift_hip_report& r = c->rep;
     for (int k = 0; k < c->nb; k++) {
         c->n_feat[k] = c->h_ct[k].ext_total;
@@ -1595,9 +1608,12 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
 int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* c)
 {
     if (!c) return POPSIFT_HIP_ERR_INVALID;
-    if (!c->have_image) return fail(c, POPSIFT_HIP_ERR_STATE, "no image submitted");
+    if (!c->have_image || !c->batch_ok) return fail(c, POPSIFT_HIP_ERR_STATE, "no image submitted");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    /* a download started by fetch_begin may still read the slab the re-run is about to write (the slabs were swapped and
+     * `moved` is cleared below without a new submit_seq): wait for it first */
+    if (int rc = drain_copy(c)) return rc;
     c->blur_events_used = 0;
     HIP_TRY(c, hipEventRecord(c->ev_begin, c->stream));
     if (int rc = enqueue_keypoint_stages(c)) return rc;

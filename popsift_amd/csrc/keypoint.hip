@@ -1045,7 +1045,11 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
                 const float fc = (float)(i - ((int)cur >> 16));
                 u = fmaf(crsbp, fc, fmaf(srsbp, fr, u0));
                 v = fmaf(crsbp, fr, fmaf(-srsbp, fc, v0));
-                off = (unsigned int)fmaf(fr, pitch4f, fc * 4.0f);
+                /* the end-of-list sentinel (column -32767 of a row that does not exist) makes this product negative, and the
+                 * lane must then read offset 0: v_cvt_u32_f32 saturates a negative input to 0 by definition, whereas the
+                 * C++ cast of an out-of-range float is undefined (fptoui poison) -- so the instruction is named, as for
+                 * v_cvt_rpi_i32_f32 in k_orientation */
+                asm("v_cvt_u32_f32 %0, %1" : "=v"(off) : "v"(fmaf(fr, pitch4f, fc * 4.0f)));
             };
             /* one sample: gradient (gx, gy) at cell-unit position (u, v) -> up to four 64-bit LDS atomics */
             unsigned int probe_acc = 0u; /* DESC_PROBE_NOATOMIC only */
@@ -1162,9 +1166,13 @@ __global__ __launch_bounds__(64 * KP_NW, 8) void k_descriptor(BatchDesc bd, Sift
         const float inv_scale = scalbnf(1.0f, -fbits);
         float       v0 = (float)a0 * inv_scale, v1 = (float)a1 * inv_scale;
 
-        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave.  The reference divides with
-         * __fdividef and takes __frsqrt_rn: the hardware reciprocal, square root and reciprocal square root (1 ulp) do here
-         * what the IEEE sequences of sqrtf and "/" did in 50 more instructions per descriptor. */
+        /* normalisation (s_desc_norm_rs.h:44-79, s_desc_norm_l2.h:87-134), whole wave.  The reference's RootSift is
+         * __fsqrt_rn(__fdividef(v, sum)) and its L2 norms are __fsqrt_rn / __frsqrt_rn: an approximate quotient under
+         * correctly rounded roots.  Here the quotient is the hardware reciprocal (1 ulp, like __fdividef's 2 ulp) and the
+         * roots are v_sqrt_f32 / v_rsq_f32: 1 ulp where the reference rounds correctly, and a denormal quotient (a bin
+         * below 1e-38 of the sum) comes out as 0 -- a divergence of one unit in the last place of single bins, seven orders
+         * below the 1e-3 bar, recorded in DESIGN 4; the notile / iloop / grid kernels keep sqrtf and "/".  It replaced 50
+         * instructions per descriptor. */
         if (sc.norm_mode == POPSIFT_HIP_NORM_ROOTSIFT) {
             float sum = v0 + v1;
             sum = wave_allsum(sum);

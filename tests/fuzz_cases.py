@@ -6,7 +6,7 @@ import time
 import numpy as np
 
 from popsift_amd.synth import synth
-from util import bits, compare_features, descriptor_parity
+from util import bits, feature_parity
 
 
 def random_case(rng, case, max_w=700, max_h=500):
@@ -53,12 +53,9 @@ def check_case(O, hip, kw, img, threads=16):
             ext_ok = key(eo) == key(eh)
             ok = ok and ext_ok
             if ext_ok:
-                st = compare_features(*orc.fetch(), *ctx.fetch())
+                # the bars of the named cases (util.feature_parity; grid descriptors in the oracle's frame)
+                dok, pmsg, st = feature_parity(orc, *ctx.fetch(), grid_mode=kw["desc_mode"] == 2)
                 n = max(st["n_desc"], 1)
-                # the bars of the named cases (util.descriptor_parity)
-                grid = kw["desc_mode"] == 2
-                pok, pmsg = descriptor_parity(st, grid_mode=grid, min_dim=min(ctx.octave_dims(0)))
-                dok = st["missing"] == 0 and st["max_sigma_rel"] < 1e-5 and pok
                 ok = ok and dok
                 msg = pmsg if not dok else "desc_bad %d/%d max %.1e" % (st["desc_bad"], n, st["max_desc"])
             else:

@@ -128,3 +128,35 @@ def test_a_failed_allocation_inside_a_batch_is_recoverable(gpu_hip):
             assert _same(_canon(*ctx.fetch_item(k)), want_small[k]), (nth, k)
         ctx.close()
     assert failures >= 5      # most of the chosen allocations exist (the later ones depend on the slots' buffer count)
+
+
+def test_a_failed_submit_of_the_same_size_leaves_no_stale_results(gpu_hip):
+    """Two images, then four of the SAME size with an allocation failure in a new slot: the geometry does not change, so
+    nothing but the failed submit itself says that the context holds no results -- wait and fetch must answer ERR_STATE
+    (not the previous batch's counts for slots whose kernels never ran), and the next submit must work."""
+    imgs = [synth(450 + k, 240, 180) for k in range(4)]
+    single = gpu_hip.Context()
+    want = [_canon(*single.submit(im).fetch()) for im in imgs]
+    single.close()
+    failed = 0
+    for nth in (1, 3, 6, 10):
+        ctx = gpu_hip.Context()
+        ctx.submit_batch(imgs[:2])
+        assert len(ctx.wait_batch()) == 2
+        ctx.debug_set(gpu_hip.DEBUG_FAIL_ALLOC, nth)       # slots 2 and 3 are new: they allocate
+        try:
+            ctx.submit_batch(imgs)
+        except gpu_hip.PopsiftHipError as e:
+            assert e.status == gpu_hip.ERR_OOM
+            failed += 1
+            for call in (ctx.wait_batch, lambda: ctx.fetch_item(0), lambda: ctx.fetch_item(3), ctx.wait):
+                with pytest.raises(gpu_hip.PopsiftHipError) as ei:
+                    call()
+                assert ei.value.status == gpu_hip.ERR_STATE
+        ctx.debug_set(gpu_hip.DEBUG_FAIL_ALLOC, 0)
+        ctx.submit_batch(imgs)
+        assert len(ctx.wait_batch()) == 4
+        for k in range(4):
+            assert _same(_canon(*ctx.fetch_item(k)), want[k]), (nth, k)
+        ctx.close()
+    assert failed >= 2

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 from popsift_amd.synth import oxford_like_stream, synth
-from util import compare_features, descriptor_parity
+from util import feature_parity
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "popsift_amd")
@@ -90,13 +90,8 @@ def _load_dump(path):
 
 def _oracle_check(oracle_mod, params, img, feats, desc):
     orc = oracle_mod.Oracle(params, threads=min(os.cpu_count() or 4, 16)).run(img)
-    fo, do = orc.fetch()
-    st = compare_features(fo, do, feats, desc)
-    assert st["missing"] == 0 and st["n_a"] == st["n_b"], st
-    assert st["num_ori_diff"] <= max(1, st["n_a"] // 2000), st
-    ok, msg = descriptor_parity(st)
+    ok, msg, st = feature_parity(orc, feats, desc)
     assert ok, msg
-    assert st["max_sigma_rel"] <= 1e-5, st
     return st
 
 

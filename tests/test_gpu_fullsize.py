@@ -1,10 +1,11 @@
-"""BASELINE.json's full sizes: config 2 (1920x1080) against the oracle, config 3 (3840x2160,
-base 7680x4320) through size-independent properties (the oracle needs minutes there)."""
+"""BASELINE.json's full sizes against the oracle: config 2 (1920x1080) and config 3 (3840x2160, base plane 7680x4320,
+10 octaves: the largest single-GPU configuration) -- sampled planes bit for bit, the full extrema set, features and
+descriptors under the unified bars of util.feature_parity -- plus config 3's size-independent properties."""
 import numpy as np
 import pytest
 
 from popsift_amd.synth import synth
-from util import bits, compare_features, sorted_features
+from util import bits, feature_parity, sorted_features
 
 pytestmark = pytest.mark.gpu
 
@@ -23,9 +24,35 @@ def test_config2_1080p_against_oracle(oracle_mod, gpu_hip):
         assert np.array_equal(bits(orc.plane(o, 0, l)), bits(ctx.plane(o, 0, l)))
     for o, l in ((0, 4), (2, 0), (8, 4)):
         assert np.array_equal(bits(orc.plane(o, 1, l)), bits(ctx.plane(o, 1, l)))
-    st = compare_features(*orc.fetch(), *ctx.fetch())
-    assert st["matched"] == st["n_a"] == st["n_b"]
-    assert st["desc_bad"] <= st["n_desc"] // 500 and st["max_desc"] < 3e-2, st
+    eo, eh = orc.extrema(), ctx.extrema()
+    key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
+    assert key(eo) == key(eh)                       # the full extrema set, bit-exact refined positions
+    ok, msg, st = feature_parity(orc, *ctx.fetch())   # the unified bars (util.feature_parity), orientations included
+    assert ok, msg
+
+
+def test_config3_4k_against_oracle(oracle_mod, gpu_hip):
+    img = synth(3, 3840, 2160)
+    # the default cap of 100000 extrema per octave is hit by octave 0 of this image; WHICH extrema survive the cap is
+    # arrival order (as in the reference, s_extrema.cu:541), so lift the cap on both sides
+    kw = dict(max_extrema=400000)
+    orc = oracle_mod.Oracle(oracle_mod.default_params(**kw), threads=16).run(img)
+    ctx = gpu_hip.Context(gpu_hip.default_params(**kw))
+    ctx.submit(img)
+    nf, nd = ctx.wait()
+    rep = ctx.report()
+    assert rep.num_octaves == orc.num_octaves == 10 and (rep.base_w, rep.base_h) == (7680, 4320)
+    assert max(rep.ext_ct) < 400000 and (nf, nd) == orc.counts()
+    for o, l in ((0, 0), (0, 5), (1, 3), (2, 1), (5, 2), (9, 5)):
+        assert np.array_equal(bits(orc.plane(o, 0, l)), bits(ctx.plane(o, 0, l))), (o, l)
+    for o, l in ((0, 2), (3, 0), (9, 4)):
+        assert np.array_equal(bits(orc.plane(o, 1, l)), bits(ctx.plane(o, 1, l))), (o, l)
+    eo, eh = orc.extrema(), ctx.extrema()
+    key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
+    assert key(eo) == key(eh)
+    ok, msg, st = feature_parity(orc, *ctx.fetch())
+    assert ok, msg
+    assert st["n_a"] > 250000
 
 
 def test_config3_4k_properties(gpu_hip):

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 from popsift_amd.synth import gaussian_blob, synth
-from util import bits, compare_features, descriptor_parity, sorted_features
+from util import bits, compare_features, descriptor_parity, feature_parity, sorted_features
 
 pytestmark = pytest.mark.gpu
 
@@ -53,8 +53,9 @@ CASES = [
     # the coarsest scales the library accepts (sigma0 = 2 at two levels: sigma up to 8, descriptor patches of up to
     # 173 rows -- more than one pass of k_descriptor's row table)
     ("sigma2_levels2_large_patches", dict(levels=2, sigma=2.0), (44, 320, 240)),
-    # grid descriptor on an image so thin that every keypoint sits at the clamped border (the one kind of case the
-    # open-ended fuzz runs flag): own bar, util.descriptor_parity(min_dim <= 96: the octave-0 plane is 600 x 48)
+    # grid descriptor on an image so thin that every keypoint sits at the clamped border: the case where one ulp of
+    # orientation moves a quarter of the oracle's own descriptors (tests/test_oracle_grid_sensitivity.py); compared in the
+    # oracle's frame like every grid case (util.feature_parity), so the ordinary 1e-3 bar applies
     ("grid_descriptor_thin_300x24", dict(desc_mode=2), (45, 300, 24)),
 ]
 
@@ -82,15 +83,8 @@ def assert_keypoints_match(orc, ctx, grid_mode=False):
     key = lambda e: sorted(zip(e["octave"].tolist(), e["lpos"].tolist(), e["xpos"].tolist(), e["ypos"].tolist()))
     assert key(eo) == key(eh)                       # same set, bit-exact positions
     assert orc.ext_counts() == list(ctx.report().ext_ct)[:orc.num_octaves]
-    fo, do = orc.fetch()
     fh, dh = ctx.fetch()
-    st = compare_features(fo, do, fh, dh)
-    assert st["n_a"] == st["n_b"] == st["matched"] and st["missing"] == 0
-    assert st["max_sigma_rel"] < 1e-5
-    n = max(st["n_desc"], 1)
-    assert st["num_ori_diff"] <= max(1, st["n_a"] // 2000)
-    assert st["ang_bad"] <= max(2, n // 2000), st
-    ok, msg = descriptor_parity(st, grid_mode=grid_mode, min_dim=min(ctx.octave_dims(0)))
+    ok, msg, st = feature_parity(orc, fh, dh, grid_mode=grid_mode)
     assert ok, msg
     # layout contract of the reference: descriptors feature by feature, octaves ascending
     idx = np.concatenate([f["desc_idx"][: int(f["num_ori"])] for f in fh]) if len(fh) else np.zeros(0, int)
@@ -187,7 +181,7 @@ def test_hip_reproduces_golden(gpu_hip, path):
     np.testing.assert_allclose(ctx.plane(1, 1, 2), z["dog_o1_l2"], rtol=0, atol=2e-3)
     f, d = sorted_features(feats, desc)
     n = len(z["xpos"])
-    assert abs(len(f) - n) <= max(2, n // 50)
+    assert abs(len(f) - n) <= max(2, n // 500)
     # nearest-neighbour match in (octave, x, y, sigma)
     hit = dbad = 0
     off = np.concatenate([[0], np.cumsum(z["num_ori"])])
@@ -204,9 +198,14 @@ def test_hip_reproduces_golden(gpu_hip, path):
         if f["num_ori"][j] == z["num_ori"][i]:
             for k in range(int(z["num_ori"][i])):
                 a, b = z["desc"][off[i] + k], d[goff[j] + k]
-                dbad += np.linalg.norm(a - b) > 2e-2 * np.linalg.norm(a)
-    assert hit >= 0.98 * n
-    assert dbad <= max(2, len(z["desc"]) // 50)
+                dbad += np.linalg.norm(a - b) > 1e-3 * np.linalg.norm(a)
+    # bars: what a last-bit difference of the Gauss taps between two hosts can move (measured on the GPU box with the
+    # fixtures of the build container: every keypoint found, 0 .. 2 descriptors per fixture outside 1e-3)
+    assert hit >= n - max(2, n // 500), (hit, n)
+    # the GRID fixture cannot be compared in the oracle's frame (a fixture is the oracle's output, not an oracle run): its bar
+    # is the oracle's own one-ulp sensitivity at this plane size, 7.7 .. 9.7 % (tests/test_oracle_grid_sensitivity.py)
+    grid = int(kw.get("desc_mode", 0)) == 2
+    assert dbad <= (len(z["desc"]) // 10 if grid else max(2, len(z["desc"]) // 500)), (dbad, len(z["desc"]))
 
 
 def test_max_extrema_cap_and_buffer_growth(oracle_mod, gpu_hip):

@@ -64,38 +64,19 @@ def compare_features(fa, da, fb, db, tol_desc=1e-3, tol_ang=1e-3):
 EXPLAIN_FACTOR = 8.0  # relative L2 change of a descriptor per radian of frame rotation, generously (measured 2 .. 5)
 
 
-def descriptor_parity(st, grid_mode=False, min_dim=None):
-    """The descriptor bars of the GPU parity tests, one place for named cases, configs 4 / 5 and the fuzz runs.
+def descriptor_parity(st):
+    """The descriptor bars of the GPU parity tests, one place for named cases, configs 2 .. 5 and the fuzz runs.
     Returns (ok, message); the message names every offending keypoint.
 
-    loop / iloop / notile / igrid (continuous in all inputs):
       - descriptors outside 1e-3 relative L2 whose keypoint orientation AGREES with the oracle's: <= max(1, n // 5000);
       - descriptors outside 1e-3 that are explained by an orientation difference (above): they are the orientation
         differences already bounded by ang_bad <= max(2, n // 2000), so the same bound;
       - nothing beyond 3e-2, angles within 3e-2.
-    grid (grid_mode, min_dim = the smaller side of the OCTAVE-0 PLANE, i.e. of the image after the initial up- or
-    down-scaling): s_desc_grid.cu:77 SNAPS the 4096 sample points of a descriptor to pixels, so an orientation that
-    differs in its last bits (the reference sums its orientation histogram with float atomics in whatever order the
-    hardware takes them, s_orientation.cu:136 -- no two runs of the reference agree in those bits either) moves a point
-    across a rounding boundary now and then, and a point that lands on another pixel -- at a clamped border: on a quite
-    different one -- is a step of 1e-2 in the descriptor.  The bars are the measured envelope of 1300 random cases at the
-    round-3 kernels (tools/fuzz_parity.py 700 31337 and 600 2026) plus two descriptors of slack for small n:
-      - planes of more than 200 pixels on both sides: <= 5 % outside 1e-3 (measured: 1.2 % of 246 568 descriptors, single
-        cases up to 4.6 %),
-      - 97 .. 200 on the smaller side (most keypoints of the upper octaves near a border): <= 8.3 % (measured 2.8 %, single
-        cases up to 10 % at n ~ 50), both: all within 1e-1 (measured <= 8.3e-2), angles within 3e-2;
-      - thin planes, <= 96 (EVERY keypoint at a clamped border): <= 40 % (measured 7.2 %, single cases up to 38 %), all within 2e-1.
-    A third run (600 cases, seed 777001) after the bars were set: 0 failures (profiles/r03_fuzz_parity.txt)."""
+    The GRID descriptor is held to the same bars, compared in the same frame: see feature_parity."""
     n = max(st["n_desc"], 1)
     expl = st["desc_bad"] - st["unexplained"]
-    if grid_mode and min_dim is not None and min_dim <= 96:
-        ok = st["desc_bad"] <= max(5, (2 * n) // 5) and st["max_desc"] < 2e-1
-    elif grid_mode:
-        frac = 12 if (min_dim is not None and min_dim <= 200) else 20
-        ok = st["desc_bad"] <= max(3, n // frac + 2) and st["max_desc"] < 1e-1 and st["max_ang"] < 3e-2
-    else:
-        ok = (st["unexplained"] <= max(1, n // 5000) and expl <= max(2, n // 2000)
-              and st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2)
+    ok = (st["unexplained"] <= max(1, n // 5000) and expl <= max(2, n // 2000)
+          and st["max_desc"] < 3e-2 and st["max_ang"] < 3e-2)
     msg = "%d of %d descriptors outside 1e-3 (%d with agreeing orientation, %d explained by an orientation difference), max %.2e; " \
           "angles: %d outside 1e-3 rad, max %.2e" % (st["desc_bad"], n, st["unexplained"], expl, st["max_desc"], st["ang_bad"], st["max_ang"])
     for o in st["offenders"][:20]:
@@ -103,6 +84,57 @@ def descriptor_parity(st, grid_mode=False, min_dim=None):
             o["octave"], o["x"], o["y"], o["sigma"], o["k"], o["d_angle"], o["d_desc"],
             "explained" if o["explained"] else "UNEXPLAINED")
     return ok, msg
+
+
+def feature_parity(orc, fh, dh, grid_mode=False):
+    """ALL bars between an oracle run `orc` and the device's features / descriptors (fh, dh) of the same image: the one
+    function behind the named cases, BASELINE configs 2 .. 5 and the fuzz slice.  Returns (ok, message, stats).
+
+    Positions are matched exactly (the pyramid and the refinement are bit-exact); sigma within 1e-5 (device powf);
+    features with another NUMBER of orientations <= max(1, n_feat // 2000); orientations outside 1e-3 rad
+    <= max(2, n_desc // 2000); descriptors: descriptor_parity.
+
+    grid_mode (DescMode::Grid, s_desc_grid.cu:19-147): the descriptor snaps its 4096 sample points to pixels, so it is a
+    STEP function of the orientation -- one ulp of the angle moves 4.6 .. 5.1 % of the oracle's own grid descriptors beyond
+    1e-3 on ordinary planes, 8 .. 10 % at 180 x 140, 23 .. 25 % on thin planes (tests/test_oracle_grid_sensitivity.py), and the
+    last bits of an orientation are not reproducible even between two runs of the reference (float atomics,
+    s_orientation.cu:136); an ulp of the keypoint's SCALE (the device's powf against the host's, bounded at 1e-5 above)
+    does the same, since every sample point is a multiple of 3 sigma away from the keypoint.  So the grid descriptors
+    are compared IN THE SAME FRAME: the oracle recomputes its descriptors with the device's angles and scales
+    (oracle_redo_descriptors), which takes both out of the comparison, and the ordinary bar applies -- 1e-3, at most
+    max(1, n // 5000) outside.  (Rounds 2 and 3 bounded the amplified orientation
+    noise by bars fitted to what was measured: 5 % / 8.3 % / 40 %.)"""
+    fo, do = orc.fetch()
+    st = compare_features(fo, do, fh, dh)
+    n = max(st["n_desc"], 1)
+    problems = []
+    if not (st["n_a"] == st["n_b"] == st["matched"] and st["missing"] == 0):
+        problems.append("features: oracle %d, device %d, matched %d" % (st["n_a"], st["n_b"], st["matched"]))
+    if st["max_sigma_rel"] >= 1e-5:
+        problems.append("sigma differs by %.2e relative" % st["max_sigma_rel"])
+    if st["num_ori_diff"] > max(1, st["n_a"] // 2000):
+        problems.append("%d features with another number of orientations" % st["num_ori_diff"])
+    if st["ang_bad"] > max(2, n // 2000) or st["max_ang"] >= 3e-2:
+        problems.append("%d orientations outside 1e-3 rad, max %.2e" % (st["ang_bad"], st["max_ang"]))
+    if grid_mode and not problems:
+        pairs, _ = match_features(fo, fh)
+        ori = np.ascontiguousarray(fo["orientation"], np.float32).copy()
+        # a feature's sigma is its octave's sigma times 2^(octave - upscale): a power of two, undone exactly
+        scale = np.exp2(fo["debug_octave"].astype(np.float64) - int(orc.params.upscale_factor))
+        sig = (fo["sigma"].astype(np.float64) / scale).astype(np.float32)
+        for ia, ib in pairs:
+            if fo[ia]["num_ori"] == fh[ib]["num_ori"]:
+                ori[ia] = fh[ib]["orientation"]
+                sig[ia] = np.float32(np.float64(fh[ib]["sigma"]) / scale[ia])
+        orc.redo_descriptors(ori, 0, sig, 0)
+        fo, do = orc.fetch()
+        st_frame = compare_features(fo, do, fh, dh)
+        st_frame["ang_bad"], st_frame["max_ang"], st_frame["desc_bad_own_frames"] = st["ang_bad"], st["max_ang"], st["desc_bad"]
+        st = st_frame
+    ok, msg = descriptor_parity(st)
+    if not ok:
+        problems.append(msg)
+    return not problems, "; ".join(problems) if problems else msg, st
 
 
 def sorted_features(feats, desc):

@@ -313,10 +313,12 @@ int popsift_hip_rerun_keypoint_stages(popsift_hip_ctx* ctx);
  * plane-to-plane levels: 0 by plane size (default), 1 the one-tile-per-workgroup kernels only, 2 the strip-march kernels
  * wherever they apply, also on small planes (results do not depend on it: every path is bit-identical; the tests run
  * their small images through 2); BLUR_SEG = rows per segment of the march kernels (a multiple of 32; 0 = chosen from the
- * plane and the batch). */
+ * plane and the batch); PYR_TAIL = 0: the smallest octaves -- from the first whose plane fits one workgroup's LDS -- are
+ * built by one launch (default), 1: by level launches like the others (results do not depend on it). */
 enum { POPSIFT_HIP_DEBUG_DET_QCAP = 1, POPSIFT_HIP_DEBUG_CAND_CAP = 2, POPSIFT_HIP_DEBUG_OHIST_CAP = 3,
        POPSIFT_HIP_DEBUG_FAIL_ALLOC = 4, POPSIFT_HIP_DEBUG_DESC_ROWS = 5, POPSIFT_HIP_DEBUG_PYR_ORDER = 6,
-       POPSIFT_HIP_DEBUG_KP_WAVES = 7, POPSIFT_HIP_DEBUG_BLUR_PATH = 8, POPSIFT_HIP_DEBUG_BLUR_SEG = 9 };
+       POPSIFT_HIP_DEBUG_KP_WAVES = 7, POPSIFT_HIP_DEBUG_BLUR_PATH = 8, POPSIFT_HIP_DEBUG_BLUR_SEG = 9,
+       POPSIFT_HIP_DEBUG_PYR_TAIL = 10 };
 int popsift_hip_debug_set(popsift_hip_ctx* ctx, int what, int value);
 
 #ifdef __cplusplus

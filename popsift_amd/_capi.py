@@ -127,7 +127,7 @@ SYMBOLS = [
 MATCH_AUTO, MATCH_EXACT, MATCH_SCREEN = 0, 1, 2
 STAGES = ("pyramid", "detect", "refine", "orientation", "scan", "descriptor")
 DEBUG_DET_QCAP, DEBUG_CAND_CAP, DEBUG_OHIST_CAP, DEBUG_FAIL_ALLOC, DEBUG_DESC_ROWS, DEBUG_PYR_ORDER, DEBUG_KP_WAVES = 1, 2, 3, 4, 5, 6, 7
-DEBUG_BLUR_PATH, DEBUG_BLUR_SEG = 8, 9
+DEBUG_BLUR_PATH, DEBUG_BLUR_SEG, DEBUG_PYR_TAIL = 8, 9, 10
 MAX_BATCH = 16
 IMG_HOST_U8, IMG_HOST_F32, IMG_DEV_U8, IMG_DEV_F32, IMG_PINNED_U8, IMG_PINNED_F32 = range(6)
 

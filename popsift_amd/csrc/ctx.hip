@@ -115,6 +115,7 @@ struct popsift_hip_ctx {
     int       desc_rows = 1 << 30;
     int       pyr_order = 0;
     BlurTune  blur_tune{0, 0}; /* BLUR_PATH / BLUR_SEG debug switches */
+    int       pyr_tail = 0;    /* PYR_TAIL: 0 the smallest octaves in one launch where they fit, 1 level launches only */
     int       cand_cap_init = 1 << 20;
     bool      cand_cap_user = false;
     int       ohist_cap_init = 0;
@@ -593,13 +594,40 @@ int enqueue_pyramid(popsift_hip_ctx* c, int is_f32, int pitch, bool aligned4)
     /* Level 1 of octave 1 reads what level L-3 of octave 0 has just written (every second pixel, 1/4 of a plane): launched
      * right behind it, that plane still sits in the L2s; after levels L-2 and L-1 of octave 0 (2 x 66 MB through the
      * caches) it came from HBM, and the launch took 14 us instead of 8 (round 2's "octave-1 anomaly"). */
-    const bool early1 = c->pyr_order == 1 && pd.n_oct >= 2 && L - 3 >= 1;
+    /* The smallest octaves -- from the first one whose plane fits the LDS of one workgroup -- are built by ONE launch
+     * (pyr_tail.hip) instead of three dependent launches per octave; `n_front` octaves take the level launches. */
+    int n_front = pd.n_oct;
+    TailArgs ta{};
+    if (c->pyr_tail != 1 && c->profile != 1 && pd.dog_fly && L <= PYR_TAIL_MAX_L) {
+        bool taps_ok = true;
+        for (int l = 1; l < L; l++) taps_ok = taps_ok && c->tab.span[l] - 1 <= PYR_TAIL_PAD && c->tab.span[l] >= 2;
+        int first = pd.n_oct;
+        for (int o = pd.n_oct - 1; o >= 1 && taps_ok && pyr_tail_fits(pd.o[o].w, pd.o[o].h); o--) first = o;
+        if (first < pd.n_oct) {
+            n_front = first;
+            ta.n_oct = pd.n_oct;
+            ta.first_oct = first;
+            ta.L = L;
+            for (int l = 1; l < L; l++) {
+                ta.halo[l] = c->tab.span[l] - 1;
+                for (int k = 0; k <= PYR_TAIL_PAD; k++) ta.g[l][k] = k < c->tab.span[l] ? c->tab.filter[l * PS_GA + k] : 0.0f;
+            }
+            for (int o = 0; o < pd.n_oct; o++) {
+                ta.w[o] = pd.o[o].w;
+                ta.h[o] = pd.o[o].h;
+                ta.pitch[o] = pd.o[o].pitch;
+                ta.data_off[o] = pd.o[o].data_off;
+                ta.plane_stride[o] = pd.o[o].plane_stride;
+            }
+        }
+    }
+    const bool early1 = c->pyr_order == 1 && n_front >= 2 && L - 3 >= 1;
     for (int level = 1; level < L; level++) {
         if (int rc = single(0, level)) return rc;
         if (early1 && level == L - 3)
             if (int rc = single(1, 1)) return rc;
     }
-    for (int o = 1; o < pd.n_oct; o++) {
+    for (int o = 1; o < n_front; o++) {
         /* per-launch profiling keeps one kernel per event pair */
         const bool pair = c->profile != 1 && o >= 2 && blur_tile_h(pd.o[o].w, pd.o[o].h) == 32 &&
                           blur_tile_h(pd.o[o - 1].w, pd.o[o - 1].h) == 32;
@@ -617,9 +645,14 @@ int enqueue_pyramid(popsift_hip_ctx* c, int is_f32, int pitch, bool aligned4)
             }
         }
     }
-    if (pd.n_oct >= 2)
+    if (n_front < pd.n_oct) {
+        /* reads level 0 of octave n_front, which level L-3 of octave n_front - 1 has just written */
+        HIP_TRY(c, launch_pyr_tail(ta, c->bd, c->nb, c->stream));
+        SYNC_CHK(c, "k_pyr_tail");
+    }
+    if (n_front >= 2)
         for (int level = L - 2; level < L; level++)
-            if (int rc = single(pd.n_oct - 1, level)) return rc;
+            if (int rc = single(n_front - 1, level)) return rc;
     return 0;
 }
 
@@ -1597,6 +1630,9 @@ int popsift_hip_debug_set(popsift_hip_ctx* c, int what, int value)
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_BLUR_SEG:
         c->blur_tune.seg_rows = std::max(value, 0);
+        return POPSIFT_HIP_OK;
+    case POPSIFT_HIP_DEBUG_PYR_TAIL:
+        c->pyr_tail = value;
         return POPSIFT_HIP_OK;
     case POPSIFT_HIP_DEBUG_DESC_ROWS:
         c->desc_rows = c->sc.desc_rows = std::max(value, 4);

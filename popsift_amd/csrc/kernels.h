@@ -53,6 +53,21 @@ hipError_t launch_blur_march(BlurArgs a, const BatchDesc& bd, int nb, int halo, 
 /* two plane-to-plane level launches with 32-row tiles in one (small octaves) */
 hipError_t launch_blur_duo(const BlurArgs& a, int span_a, const BlurArgs& b, int span_b, const BatchDesc& bd, int nb, hipStream_t s);
 
+/* pyr_tail.hip: every octave from `first_oct` on in one launch, one workgroup per image (planes in LDS) */
+#define PYR_TAIL_PAD 16             /* LDS border = the largest halo the tail takes */
+#define PYR_TAIL_PLANE_FLOATS 17408 /* one LDS plane buffer incl. its border (two of them + the next octave's level 0: 154 KB) */
+#define PYR_TAIL_MAX_L 10           /* Gaussian planes per octave (levels + 3) */
+#define PYR_TAIL_MAX_PX 4096        /* pixels of the first plane the tail takes */
+struct TailArgs {
+    int     n_oct, first_oct, L;
+    int     halo[PYR_TAIL_MAX_L];                     /* span - 1 of level l, rounded up to an instantiated HALO */
+    float   g[PYR_TAIL_MAX_L][PYR_TAIL_PAD + 1];      /* taps of level l, zero beyond its span */
+    int     w[PS_MAX_OCT], h[PS_MAX_OCT], pitch[PS_MAX_OCT];
+    int64_t data_off[PS_MAX_OCT], plane_stride[PS_MAX_OCT]; /* floats from the arena base / between planes */
+};
+bool       pyr_tail_fits(int w, int h);
+hipError_t launch_pyr_tail(const TailArgs& a, const BatchDesc& bd, int nb, hipStream_t s);
+
 /* extrema.hip */
 hipError_t launch_dog_plane(float* dog, const float* upper, const float* lower, size_t n, hipStream_t s); /* debug / test downloads */
 int        extrema_units(int w, int h); /* wave-sized work units of the detection kernel */

@@ -601,7 +601,7 @@ int blur_tile_h(int w, int h)
 }
 
 /* march kernels from this many pixels per launch (all images of the batch) on, cut into at least this many workgroups */
-constexpr long BLUR_MARCH_MIN_PX = 1500000;
+constexpr long BLUR_MARCH_MIN_PX = 12000000;
 constexpr int  BLUR_MARCH_WGS = 768;
 
 /* lanes per 4x4 block for small planes: 1 / 2 / 4 -> pyramid stage of a 1080p image 291 / 295 / 275 us */

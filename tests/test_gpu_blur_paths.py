@@ -2,7 +2,8 @@
 
 The pyramid's plane-to-plane levels have two sets of kernels: one tile per workgroup (pyramid.hip) and the strip march
 (blur_march.hip) that the large planes take.  Which one a launch uses depends on the plane's size and on the batch -- a
-matter of speed only.  The debug switch BLUR_PATH forces either (1 = tiles only, 2 = march wherever it applies), BLUR_SEG
+matter of speed only; the smallest octaves are built by one launch of one workgroup per image (pyr_tail.hip) or, with
+PYR_TAIL = 1, by level launches like the others.  The debug switch BLUR_PATH forces either (1 = tiles only, 2 = march wherever it applies), BLUR_SEG
 the rows per segment of the march, so the small images the oracle finishes in seconds reach the march kernels too:
 strips cut by the plane's border, segments of one and several steps, a last step of fewer than 32 rows, planes of fewer
 rows than the filter is long, every HALO instance (spans of levels 2 .. 6 at sigma 1 .. 2, opencv spans)."""
@@ -14,7 +15,7 @@ from util import bits, sorted_features
 
 pytestmark = pytest.mark.gpu
 
-BLUR_PATH, BLUR_SEG = 8, 9
+BLUR_PATH, BLUR_SEG, PYR_TAIL = 8, 9, 10
 
 CASES = [
     ("default_400x300", dict(), (61, 400, 300)),
@@ -29,6 +30,8 @@ CASES = [
     ("levels6_sigma1", dict(levels=6, sigma=1.0), (66, 200, 260)),
     ("opencv_gauss", dict(sift_mode=1, gauss_mode=3), (67, 300, 220)),
     ("float_input", dict(), (68, 280, 210)),
+    ("deep_octaves_40x24", dict(octaves=7), (40, 40, 24)),            # planes shrink to 2 x 1: all but octave 0 in the tail
+    ("tail_from_a_plane_that_just_fits_256x176", dict(upscale_factor=0.0), (69, 256, 176)),  # octave 1 = 128 x 88
 ]
 
 
@@ -44,10 +47,12 @@ def test_march_and_tile_kernels_give_the_oracles_planes(oracle_mod, gpu_hip, nam
     L = max(2, kw.get("levels", 3)) + 3
     orc = oracle_mod.Oracle(oracle_mod.default_params(**kw), threads=8).run(img)
     want = [[orc.plane(o, 0, l) for l in range(L)] for o in range(orc.num_octaves)]
-    for path, seg in ((1, 0), (2, 0), (2, 32), (2, 64), (2, 96)):
+    # (blur path, rows per march segment, PYR_TAIL: 1 = no tail launch)
+    for path, seg, tail in ((1, 0, 1), (1, 0, 0), (2, 0, 0), (2, 32, 1), (2, 64, 0), (2, 96, 0)):
         ctx = gpu_hip.Context(gpu_hip.default_params(**kw))
         ctx.debug_set(BLUR_PATH, path)
         ctx.debug_set(BLUR_SEG, seg)
+        ctx.debug_set(PYR_TAIL, tail)
         ctx.submit(img)
         ctx.wait()
         assert ctx.report().num_octaves == orc.num_octaves
@@ -55,8 +60,8 @@ def test_march_and_tile_kernels_give_the_oracles_planes(oracle_mod, gpu_hip, nam
         for o in range(orc.num_octaves):
             for l in range(L):
                 a, b = want[o][l], got[o][l]
-                assert np.array_equal(bits(a), bits(b)), "path %d seg %d octave %d level %d: %d values differ, max %g" % (
-                    path, seg, o, l, int((bits(a) != bits(b)).sum()), float(np.abs(a - b).max()))
+                assert np.array_equal(bits(a), bits(b)), "path %d seg %d tail %d octave %d level %d: %d values differ, max %g" % (
+                    path, seg, tail, o, l, int((bits(a) != bits(b)).sum()), float(np.abs(a - b).max()))
         ctx.close()
 
 

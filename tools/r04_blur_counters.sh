@@ -13,7 +13,7 @@ run_pass() {
     if [ $rc -ne 0 ]; then echo "pass $name rc=$rc"; tail -3 $OUT/$name.log; fi
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi
     echo "== $name" >> $OUT/summary.txt
-    python3 $R/tools/pmc.py $OUT/$name | grep -E "^kernel|blur" >> $OUT/summary.txt 2>&1
+    python3 $R/tools/pmc.py $OUT/$name | grep -E "^kernel|blur|tail" >> $OUT/summary.txt 2>&1
     rm -rf $OUT/$name
 }
 run_pass sq_inst SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR

@@ -18,7 +18,7 @@ Rank 0 prints ONE JSON line with the driver contract fields plus
   roofline      -- the WHOLE pipeline of one image against the HBM roofline (B_alg / T_dev, T_dev from
                    HIP events on the context's stream), with a `kernels` list: per stage its device time (HIP events
                    between the launches, C-ABI profile mode 2), share, bound, achieved / peak / frac and the HBM
-                   traffic the rocprofv3 counter passes measured for it (profiles/r03_kernel_counters.json; quoted only
+                   traffic the rocprofv3 counter passes measured for it (profiles/r04_kernel_counters.json; quoted only
                    while the kernel sources are the ones that were counted, "counters_stale" otherwise)
   cpu_baseline  -- the CPU oracle (kind "port") on a bounded sample, N=1 only
   sparse_image  -- the same pipeline on a keypoint-sparse image (about 2 features per 1000 pixels), where the pyramid
@@ -87,12 +87,12 @@ def spawn_ranks(args):
 
 def kernel_counters():
     """Per-stage HBM traffic and instruction counts from the rocprofv3 counter passes of this configuration
-    (tools/collect_profiles.sh -> profiles/r03_kernel_counters.json; FETCH_SIZE x2 + WRITE_SIZE, separate passes).
+    (tools/collect_profiles.sh -> profiles/r04_kernel_counters.json; FETCH_SIZE x2 + WRITE_SIZE, separate passes).
     Counters cannot be collected inside the timed process, so the committed measurement is quoted -- as long as it is a
     measurement of THESE kernels: the summary carries the hash of the kernel sources it was taken from
     (popsift_amd/srchash.py); when the tree's differs the counters are marked stale and nothing is derived from them."""
     try:
-        with open(os.path.join(HERE, "profiles", "r03_kernel_counters.json")) as f:
+        with open(os.path.join(HERE, "profiles", "r04_kernel_counters.json")) as f:
             ctr = json.load(f)
     except Exception:
         return {}, True
@@ -106,8 +106,9 @@ class Workers:
     (submit, wait, next), so no context idles at a step boundary while another finishes its share.  The call returns
     when the last image of the last step is done."""
 
-    def __init__(self, ctxs, ptrs, launch_batch=1):
+    def __init__(self, ctxs, ptrs, launch_batch=1, size=None):
         self.ctxs, self.ptrs, self.lb = ctxs, ptrs, max(1, launch_batch)
+        self.w, self.h = size if size else (W, H)
         self.n = len(ctxs)
         self.go = threading.Barrier(self.n + 1)
         self.done = threading.Barrier(self.n + 1)
@@ -145,12 +146,12 @@ class Workers:
                     break
                 mine = [self.ptrs[k % n] for k in range(*t)]
                 if self.lb == 1:
-                    ctx.submit_dev(mine[0], W, H, W)
+                    ctx.submit_dev(mine[0], self.w, self.h, self.w)
                     nf, nd = ctx.wait()
                     f += nf
                     d += nd
                 else:
-                    ctx.submit_batch_dev(mine, W, H, W)
+                    ctx.submit_batch_dev(mine, self.w, self.h, self.w)
                     for nf, nd in ctx.wait_batch():
                         f += nf
                         d += nd
@@ -202,6 +203,43 @@ def single_image(ctx, ptr, hip, n=5):
     ctx.set_profile(0)
     rep = ctx.report()
     return float(np.median(lat)), [float(x) for x in np.median(np.array(st), 0)], rep
+
+
+def other_config(hip, torch, np, synth, device, w, h, seed, params_kw, contexts, launch_batch, images_per_step, distinct, steps=3):
+    """Reported extra (never `value`): another BASELINE.json configuration -- one image alone on the device (T_dev by HIP
+    events, median of 5, and the pipeline's algorithmic bytes over it) and the same in-flight arrangement as the timed loop
+    (`contexts` contexts x `launch_batch` images per launch)."""
+    imgs = [synth(seed + k, w, h) for k in range(distinct)]
+    dev = [torch.from_numpy(im).cuda(device) for im in imgs]
+    ptrs = [dev[i % distinct].data_ptr() for i in range(images_per_step)]
+    ctxs = [hip.Context(hip.default_params(**params_kw), device=device) for _ in range(contexts)]
+    lat = []
+    for _ in range(5):
+        ctxs[0].submit_dev(ptrs[0], w, h, w)
+        ctxs[0].wait()
+        lat.append(ctxs[0].report().ms_device)
+    rep = ctxs[0].report()
+    ms_dev = float(np.median(lat))
+    bytes_alg = b_alg(rep, w, h)
+    wk = Workers(ctxs, ptrs, launch_batch, size=(w, h))
+    wk.run(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wk.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    wk.close()
+    for c in ctxs:
+        c.close()
+    n = steps * images_per_step
+    return {"size": "%dx%d" % (w, h), "params": params_kw, "octaves": rep.num_octaves, "base_plane": "%dx%d" % (rep.base_w, rep.base_h),
+            "features": rep.ext_total, "descriptors": rep.ori_total,
+            "features_per_1000_px": round(rep.ext_total / (w * h / 1000.0), 2),
+            "single_image_ms_device": round(ms_dev, 4),
+            "single_image_pipeline_frac_of_8TBps": round(bytes_alg / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "in_flight_contexts": contexts, "images_per_launch": launch_batch,
+            "in_flight_mpix_s": round(n * w * h / 1e6 / dt, 1), "in_flight_ms_per_image": round(dt / n * 1e3, 4),
+            "in_flight_pipeline_frac_of_8TBps": round(bytes_alg * n / dt / 1e9 / HBM_PEAK_GBPS, 4)}
 
 
 def main():
@@ -362,7 +400,7 @@ def main():
                              # vector instructions of all kernels of an image (counter passes) over the timed rate
                              "valu_issue_frac": round(valu_img / (ms_img * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if valu_img else None,
                              "hbm_traffic_frac": round(traffic / (ms_img * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None},
-            "counters": "profiles/r03_kernel_counters.json" if not stale else None, "counters_stale": stale,
+            "counters": "profiles/r04_kernel_counters.json" if not stale else None, "counters_stale": stale,
             "dominant": max(kernels, key=lambda k: k["ms"])["stage"], "kernels": kernels,
         }
         extra["single_image"] = {"ms_device": round(ms_dev, 4), "features": rep.ext_total, "descriptors": rep.ori_total}
@@ -428,6 +466,15 @@ def main():
             extra["sparse_image"]["in_flight_pipeline_frac_of_8TBps"] = round(
                 bs * n_sp * len(ptrs) / dt_sp / 1e9 / HBM_PEAK_GBPS, 4)
             leg("sparse_image")
+        # ---- BASELINE.json configs 3 and 1 in the arrangement of the timed loop (reported extras) -----------------------
+        if not args.only_roofline:
+            # config 3: 3840x2160, default Config (2x upscale: base plane 7680x4320, 10 octaves); 1.1 GB of planes per image
+            extra["config3_4k"] = other_config(hip, torch, np, synth, local_rank, 3840, 2160, 3, {}, C, min(args.launch_batch, 4),
+                                               3 * min(args.launch_batch, 4), 2)
+            # config 1: 640x480, three octaves, VLFeat mode
+            extra["config1_vga"] = other_config(hip, torch, np, synth, local_rank, 640, 480, 1, {"octaves": 3, "sift_mode": 2}, C,
+                                                args.launch_batch, 256, 8)
+            leg("configs_1_3")
         # ---- PCIe-inclusive end-to-end rate (host image in, host features out), one context -----------------------
         t1 = time.perf_counter()
         n_e2e = 0 if args.only_roofline else 8
@@ -520,6 +567,7 @@ def main():
                                        "3 levels, PopSift mode, loop descriptor, RootSift)",
                            "images_per_step_per_gpu": B, "distinct_images_per_gpu": U, "contexts_per_gpu": C,
                            "images_per_launch": args.launch_batch,
+                           "features_per_1000_px": round(feats_step / max(B * world, 1) / (W * H / 1000.0), 2),
                            "results": "device resident (features + descriptors)"},
                 "features_per_s": round(feats_step * args.steps / elapsed, 1),
                 "descriptors_per_s": round(descs_step * args.steps / elapsed, 1),

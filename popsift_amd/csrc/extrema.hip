@@ -144,13 +144,35 @@ __device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int
             const int64_t ps3 = (top ? 2 : 3) * dog.ps; /* Gaussian level zc+2 does not exist when top */
             constexpr int DX[9] = {0, 1, -1, 0, 0, -1, -1, 1, 1}, DY[9] = {0, 0, 0, 1, -1, -1, 1, -1, 1};
             float         g0[5], g1[9], g2[9], g3[5];
+            if (nx >= 1 && nx <= width - 2 && ny >= 1 && ny <= height - 2) {
+                /* Every candidate and every step of the refinement stays inside [1, w-2] x [1, h-2] (a pixel on the border
+                 * cannot pass the strict 26-neighbour test against its own clamped copy, and the step rules stop at 1 and
+                 * w - 2): no coordinate clamps, and the three neighbours of a row are ONE 12-byte load.  The kernel is bound by
+                 * the number of scattered requests its lanes put to the L1 (28 dwords per candidate and iteration before:
+                 * 36 us for 150 000 candidates), not by their bytes: 12 requests instead of 28. */
+                struct f3 { float a, b, c; };
+                auto row3 = [](const float* p) -> f3 { f3 v; __builtin_memcpy(&v, p, 12); return v; };
+                const float* c0 = g + (int64_t)ny * dog.pitch + (nx - 1);
+                const float* c1 = c0 + dog.ps;
+                const float* c2 = c1 + dog.ps;
+                const float* c3 = g + ps3 + (int64_t)ny * dog.pitch + (nx - 1);
+                const int    pt = dog.pitch;
+                const f3 a0 = row3(c0), a3 = row3(c3);
+                const f3 m1 = row3(c1 - pt), z1 = row3(c1), p1 = row3(c1 + pt);
+                const f3 m2 = row3(c2 - pt), z2 = row3(c2), p2 = row3(c2 + pt);
+                g0[2] = a0.a, g0[0] = a0.b, g0[1] = a0.c, g0[3] = c0[pt + 1], g0[4] = c0[1 - pt];
+                g3[2] = a3.a, g3[0] = a3.b, g3[1] = a3.c, g3[3] = c3[pt + 1], g3[4] = c3[1 - pt];
+                g1[2] = z1.a, g1[0] = z1.b, g1[1] = z1.c, g1[6] = p1.a, g1[3] = p1.b, g1[8] = p1.c, g1[5] = m1.a, g1[4] = m1.b, g1[7] = m1.c;
+                g2[2] = z2.a, g2[0] = z2.b, g2[1] = z2.c, g2[6] = p2.a, g2[3] = p2.b, g2[8] = p2.c, g2[5] = m2.a, g2[4] = m2.b, g2[7] = m2.c;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const int64_t off = (int64_t)ys[DY[i] + 1] * dog.pitch + xs[DX[i] + 1];
-                if (i < 5) g0[i] = g[off];
-                g1[i] = g[dog.ps + off];
-                g2[i] = g[2 * dog.ps + off];
-                if (i < 5) g3[i] = g[ps3 + off];
+                for (int i = 0; i < 9; i++) {
+                    const int64_t off = (int64_t)ys[DY[i] + 1] * dog.pitch + xs[DX[i] + 1];
+                    if (i < 5) g0[i] = g[off];
+                    g1[i] = g[dog.ps + off];
+                    g2[i] = g[2 * dog.ps + off];
+                    if (i < 5) g3[i] = g[ps3 + off];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 9; i++) {

@@ -8,7 +8,7 @@
 #      FETCH_SIZE and WRITE_SIZE in SEPARATE passes; --kernel-trace only, no other trace domain)
 # usage: collect_profiles.sh <tag>   ->  gpurun_out/profiles_<tag>/*.txt, kernel_counters.json  (copy into profiles/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 RAW=/tmp/profiles_raw
 OUT=$R/gpurun_out/profiles_$TAG
 rm -rf $RAW $OUT

@@ -13,7 +13,7 @@ import os
 import sys
 
 TAG, RAW, OUT, NIMG = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-STAGES = (("pyramid", ("k_blur_tile", "k_blur_duo", "k_blur_small")), ("detect", ("k_detect",)), ("refine", ("k_refine", "k_filter")),
+STAGES = (("pyramid", ("k_blur_tile", "k_blur_duo", "k_blur_small", "k_blur_march", "k_pyr_tail")), ("detect", ("k_detect",)), ("refine", ("k_refine", "k_filter")),
           ("orientation", ("k_orientation",)), ("scan", ("k_scan_",)), ("descriptor", ("k_descriptor",)))
 
 

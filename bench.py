@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per step per GPU (one step = one batch)")
     ap.add_argument("--contexts", type=int, default=3, help="extraction contexts (streams) per GPU")
-    ap.add_argument("--launch-batch", type=int, default=8,
+    ap.add_argument("--launch-batch", type=int, default=16,
                     help="images a context extracts per submit (popsift_hip_submit_batch: every kernel launched once for all of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="timed loop only: no roofline / host-to-host / CPU legs (A/B runs)")

@@ -16,6 +16,6 @@ one() {
 for so in product $R/build_variants/v*.so; do
   if [ $so = product ]; then unset POPSIFT_HIP_LIB; n=main; else [ -f $so ] || continue; export POPSIFT_HIP_LIB=$so; n=$(basename $so .so); echo "## $(grep "^$n:" $R/build_variants/flags.txt)"; fi
   for seg in $SEGS; do
-    PROF_DEBUG="9:$seg" one ${n}_seg$seg
+    PROF_DEBUG="8:2,9:$seg" one ${n}_seg$seg
   done
 done

@@ -8,12 +8,17 @@ import numpy as np
 from popsift_amd import _capi as hip
 from popsift_amd.synth import synth
 seg = int(sys.argv[1]); ncu = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # images per launch (the stamps are image 0's)
 PH, N = 6, 8
 img = synth(2, 1920, 1080)
+imgs = [synth(2 + k, 1920, 1080) for k in range(nb)] if nb > 1 else [img]
 ctx = hip.Context()
 ctx.debug_set(hip.DEBUG_BLUR_PATH, 2); ctx.debug_set(hip.DEBUG_BLUR_SEG, seg); ctx.debug_set(hip.DEBUG_PYR_TAIL, 1)
 for _ in range(4):
-    ctx.submit(img); ctx.wait()
+    if nb == 1:
+        ctx.submit(img); ctx.wait()
+    else:
+        ctx.submit_batch([synth(2 + k, 1920, 1080) if _ == 0 else imgs[k] for k in range(nb)] if False else imgs); ctx.wait_batch()
 L = hip.lib()
 buf = np.zeros(4096 * 4 * PH * N, np.uint64)
 L.popsift_hip_debug_read_march_stamps.argtypes = [C.c_void_p, C.c_size_t]

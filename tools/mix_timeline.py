@@ -9,7 +9,8 @@ Reads *kernel_trace.csv, drops the first `skip_fraction` of the wall span (warm-
   3. class-by-class co-residency: share of class A's running time during which class B also runs;
   4. a table of 50-us buckets (the first 40 after the skip): launches of each class resident in the bucket.
 Classes: desc (k_descriptor*), ori (k_orientation), detect, refine, scan, blur0 (64-row tiles: octave 0),
-blur1 (32-row tiles with 256 lanes: octave 1 and duo<.,1>), blurS (1024-lane small-octave launches), other.
+blur1 (32-row tiles with 256 lanes, duo<.,1>, and the strip-march level launches k_blur_march of octaves 0 .. 2 in a batch),
+blurS (1024-lane small-octave launches and the one-launch tail), other.
 """
 import collections
 import csv
@@ -31,7 +32,7 @@ def klass(name):
         return 'scan'
     if n.startswith('k_blur_tile64') or (n.startswith('k_blur_tile<') and ', 64,' in n) or n.startswith('k_blur_batch64'):
         return 'blur0'
-    if n.startswith('k_blur_small') or (n.startswith('k_blur_duo') and n.rstrip('>').endswith(', 4')):
+    if n.startswith('k_blur_small') or n.startswith('k_pyr_tail') or (n.startswith('k_blur_duo') and n.rstrip('>').endswith(', 4')):
         return 'blurS'
     if n.startswith('k_blur'):
         return 'blur1'

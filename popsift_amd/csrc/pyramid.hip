@@ -671,11 +671,13 @@ hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode,
 {
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
-    /* large planes: the march kernel (blur_march.hip).  "Large" = the launch fills the device with workgroups that make at
-     * least two steps each; below that a level launch is a latency chain and the one-tile-per-workgroup kernels are shorter */
+    /* Batches of large planes: the march kernel (blur_march.hip).  It pays where a workgroup makes many steps and the launch
+     * still fills the device -- several images per launch (a batch of eight 1080p planes: 17 steps per workgroup, 960
+     * workgroups: 17-21 us per plane against 17-26).  A SINGLE plane has no such operating point (3840 x 2160: 18-27 us
+     * against 17-26; 7680 x 4320: config 3's image 2.83-2.86 ms against 2.76 with the tile kernels): DESIGN 6.2. */
     if (mode == 0 && tune.path != 1 && blur_march_supported(a, halo)) {
         const long px = (long)a.w * a.h * nb;
-        if (tune.path == 2 || px >= BLUR_MARCH_MIN_PX) {
+        if (tune.path == 2 || (nb >= 2 && px >= BLUR_MARCH_MIN_PX)) {
             int seg = tune.seg_rows > 0 ? std::max(32, tune.seg_rows / 32 * 32) : blur_march_seg_rows(a.w, a.h, nb, BLUR_MARCH_WGS);
             return launch_blur_march(a, bd, nb, halo, seg, s);
         }

@@ -1597,7 +1597,9 @@ static int keypoint_stages(oracle_ctx* c)
  * of the reference do, its sigma by the device's powf) and to measure how far an ulp of either moves a descriptor. */
 int oracle_redo_descriptors(oracle_ctx* c, const float* ori, int ori_ulps, const float* sigma, int sigma_ulps)
 {
-    if (!c || c->n_oct <= 0 || !c->desc) return -1;
+    if (!c || c->n_oct <= 0) return -1;
+    if (c->ext_total == 0 || c->ori_total == 0) return 0; /* nothing to recompute */
+    if (!c->desc) return -1;
     for (int i = 0; i < c->ext_total; i++) {
         for (int k = 0; k < c->ext[i].num_ori; k++) {
             float a = ori ? ori[4 * (size_t)i + k] : c->ext[i].orientation[k];

@@ -29,12 +29,15 @@ def random_case(rng, case, max_w=700, max_h=500):
     return kw, img
 
 
-def check_case(O, hip, kw, img, threads=16):
-    """Returns (ok, message)."""
+def check_case(O, hip, kw, img, threads=16, debug=()):
+    """Returns (ok, message).  debug: popsift_hip_debug_set switches (what, value) set on the context before the submit --
+    e.g. ((8, 2), (9, 64)) sends every plane-to-plane level through the march kernels in 64-row segments."""
     t0 = time.time()
     try:
         orc = O.Oracle(O.default_params(**kw), threads=threads).run(img)
         ctx = hip.Context(hip.default_params(**kw))
+        for what, value in debug:
+            ctx.debug_set(what, value)
         ctx.submit(img)
         ctx.wait()
         ok = ctx.report().num_octaves == orc.num_octaves

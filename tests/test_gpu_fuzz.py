@@ -20,3 +20,21 @@ def test_sixty_random_configurations(oracle_mod, gpu_hip):
         if not ok:
             failures.append((case, img.shape, kw, msg))
     assert not failures, failures
+
+
+@pytest.mark.gpu
+def test_random_configurations_through_the_march_kernels(oracle_mod, gpu_hip):
+    """Cases 90 .. 109 of tools/fuzz_parity.py 400 50505 with every plane-to-plane level forced through the strip-march
+    kernels in 32-row segments (BLUR_PATH = 2, BLUR_SEG = 32).  Case 99 is the one with two orientation peaks of exactly
+    equal height pi apart: the reference's bitonic network (restated in the oracle) and the device order them differently,
+    and the comparison pairs orientations as a set (util.compare_features)."""
+    rng = np.random.default_rng(50505)
+    failures = []
+    for case in range(110):
+        kw, img = fuzz_cases.random_case(rng, case)
+        if case < 90:
+            continue
+        ok, msg = fuzz_cases.check_case(oracle_mod, gpu_hip, kw, img, threads=min(os.cpu_count() or 4, 16), debug=((8, 2), (9, 32)))
+        if not ok:
+            failures.append((case, img.shape, kw, msg))
+    assert not failures, failures

@@ -89,3 +89,25 @@ def test_march_in_a_batch(gpu_hip):
         got = _canon(*ctx.fetch_item(k))
         assert all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(got, want[k])), "image %d" % k
     ctx.close()
+
+
+def test_the_batch_path_of_the_timed_loop_at_full_size(gpu_hip):
+    """Four 1080p images in one submit: 4 x 8.3 Mpx per level launch of octave 0, so launch_blur takes the march kernels by
+    itself (no debug switch: the path of bench.py's timed loop, 544-row segments) -- every image equals its own single
+    submit, which the tile kernels build (features, orientations, descriptors and two planes bit for bit)."""
+    imgs = [synth(100 + k, 1920, 1080) for k in range(4)]
+    want, planes = [], []
+    single = gpu_hip.Context()
+    for im in imgs:
+        want.append(_canon(*single.submit(im).fetch()))
+        planes.append((single.plane(0, 0, 5).copy(), single.plane(1, 0, 2).copy()))
+    single.close()
+    ctx = gpu_hip.Context()
+    ctx.submit_batch(imgs)
+    assert len(ctx.wait_batch()) == 4
+    for k in range(4):
+        got = _canon(*ctx.fetch_item(k))
+        assert all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(got, want[k])), "image %d" % k
+    # the planes of image 0 of the batch (the debug download reads slot 0)
+    assert np.array_equal(bits(ctx.plane(0, 0, 5)), bits(planes[0][0])) and np.array_equal(bits(ctx.plane(1, 0, 2)), bits(planes[0][1]))
+    ctx.close()

@@ -116,12 +116,12 @@ __device__ constexpr int nb_index(int dx, int dy)
 
 /* s_extrema.cu:300-504 (after the contrast + 26-neighbour tests) */
 template <int MODE, bool FLY>
-__device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int y, int level, float val,
-                       int maxlevel, InitExt& ec)
+__device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int y, int level, int maxlevel, InitExt& ec)
 {
     const int width = dog.w, height = dog.h;
     float     Dx = 0, Dy = 0, Dz = 0, DDx = 0, DDy = 0, DXx = 0;
     float     d0 = 0, d1 = 0, d2 = 0;
+    float     val = 0; /* the candidate's own DoG value: the centre of the FIRST iteration's neighbourhood */
     int       nx = x, ny = y, nz = level;
     int       iter = 0;
     constexpr int MAX_ITERATIONS = 5;
@@ -191,6 +191,7 @@ __device__ bool refine(const DogView<FLY>& dog, const SiftConsts& sc, int x, int
         Dz = 0.5f * (x1y1z2 - x1y1z0);
 
         const float x1y1z1 = R(0, 0, 0);
+        if (iter == 1) val = x1y1z1;
         DDx = x2y1z1 + x0y1z1 - 2.0f * x1y1z1;
         DDy = x1y2z1 + x1y0z1 - 2.0f * x1y1z1;
         const float DDz = x1y1z2 + x1y1z0 - 2.0f * x1y1z1;
@@ -532,11 +533,20 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
     InitExt* __restrict__     iext = bd.s[blockIdx.y].iext;
     __shared__ int s_cnt[PS_MAX_OCT], s_base[PS_MAX_OCT];
     __shared__ int s_pref[DET_SUBQ + 1]; /* 256-candidate steps before each sub-queue */
+    __shared__ int s_tot[DET_SUBQ];      /* candidates in each sub-queue */
+    /* The kernel is ONE step per workgroup (1024 workgroups for the ~590 steps of a 1080p image): its time is the
+     * chain of dependent memory round trips of that step, ~1-2 us each.  So everything a candidate needs besides the
+     * planes is in LDS before its record arrives -- the sub-queue sizes and the octaves' geometry -- and its own DoG
+     * value is taken from the first iteration's loads (refine()) instead of a round trip of its own: cand -> planes ->
+     * solve where it was qcnt -> cand -> octave record -> value -> planes -> solve. */
+    __shared__ int64_t s_off[PS_MAX_OCT], s_ps[PS_MAX_OCT];
+    __shared__ int     s_w[PS_MAX_OCT], s_h[PS_MAX_OCT], s_pitch[PS_MAX_OCT];
     const int      lane = threadIdx.x & 63;
     const int      L = pdp->L, n_oct = pdp->n_oct;
     const int      seg = cand_cap / DET_SUBQ;
     if (threadIdx.x < 64) {
-        const int steps = (min(ct->qcnt[lane].n, seg) + 255) >> 8;
+        const int tot = min(ct->qcnt[lane].n, seg);
+        const int steps = (tot + 255) >> 8;
         int       incl = steps;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
@@ -544,7 +554,16 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
             if (lane >= s) incl += v;
         }
         s_pref[lane + 1] = incl;
+        s_tot[lane] = tot;
         if (lane == 0) s_pref[0] = 0;
+    } else if ((int)threadIdx.x - 64 < n_oct) {
+        const int      o = (int)threadIdx.x - 64;
+        const OctDesc* od = &pdp->o[o];
+        s_off[o] = FLY ? od->data_off : od->dog_off;
+        s_ps[o] = od->plane_stride;
+        s_w[o] = od->w;
+        s_h[o] = od->h;
+        s_pitch[o] = od->pitch;
     }
     __syncthreads();
     const int n_steps = s_pref[DET_SUBQ];
@@ -552,9 +571,10 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
      * workgroup-uniform, so the barriers below are reached by all four waves */
     {
         for (int w = blockIdx.x; w < n_steps; w += gridDim.x) {
-            int q = 0;
-            while (s_pref[q + 1] <= w) q++;
-            const int total = min(ct->qcnt[q].n, seg);
+            /* the sub-queue of step w: the number of sub-queues that end at or before it (one LDS read and a ballot
+             * instead of a walk over up to 64 dependent reads) */
+            const int q = __popcll(__ballot(s_pref[lane + 1] <= w));
+            const int total = s_tot[q];
             const int b0 = (w - s_pref[q]) << 8;
             if (threadIdx.x < PS_MAX_OCT) s_cnt[threadIdx.x] = 0;
             __syncthreads();
@@ -566,16 +586,14 @@ __global__ __launch_bounds__(256) void k_refine(const PyrDesc* __restrict__ pdp,
                 const int2 cd = cand[(size_t)q * seg + i];
                 const int  x = cd.x & 0xffff, y = cd.x >> 16, level = cd.y & 0xff;
                 o = cd.y >> 8;
-                const OctDesc* od = &pdp->o[o];
                 DogView<FLY>   dog;
-                dog.base = arena + (FLY ? od->data_off : od->dog_off);
-                dog.ps = od->plane_stride;
-                dog.w = od->w;
-                dog.h = od->h;
-                dog.pitch = od->pitch;
+                dog.base = arena + s_off[o];
+                dog.ps = s_ps[o];
+                dog.w = s_w[o];
+                dog.h = s_h[o];
+                dog.pitch = s_pitch[o];
                 dog.nl = L - 1;
-                const float val = dog.raw(x, y, level);
-                found = refine<MODE, FLY>(dog, sc, x, y, level, val, L - 1, ec);
+                found = refine<MODE, FLY>(dog, sc, x, y, level, L - 1, ec);
             }
             /* wave64 compaction per octave (replaces extrema_count, s_extrema.cu:22-44), wave -> workgroup in LDS */
             unsigned long long todo = __ballot(found);

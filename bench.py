@@ -40,6 +40,13 @@ W, H = 1920, 1080
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_GBPS = 6290.0  # ... and the read ceiling measured on the device
 VALU_PEAK_GINST = 1228.8    # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)
+# What a kernel of nothing but independent v_fma_f32, 8 waves per SIMD on every CU, sustains for 20 .. 100 ms on this device
+# (tools/ubench/clock_under_load.hip, profiles/r04_clock_under_load.txt: 1.010e12 wave64 instructions per second = 129
+# TFLOP/s, 0.82 of the nominal peak: the clock the package power allows)
+VALU_SUSTAINED_GINST = 1010.0
+# Issue slots per vector instruction of k_descriptor's sample loop (tools/isa_count.py: 97 instructions = 120.4 full-rate
+# slots; compares / conversions / min / max count 1.76, transcendentals 3.46: tools/ubench/valu_rate.hip)
+DESC_SLOTS_PER_INSTR = 120.4 / 97.0
 
 
 def parse():
@@ -369,6 +376,10 @@ def main():
                     k["achieved"] = round(c["valu_insts"] / (ms * 1e-3) / 1e9, 1)
                     k["peak"], k["unit"] = VALU_PEAK_GINST, "G wave-instr/s"
                     k["frac"] = round(k["achieved"] / VALU_PEAK_GINST, 4)
+                    # against the issue rate the device sustains, in full-rate issue slots where the mix is known
+                    slots = DESC_SLOTS_PER_INSTR if name == "descriptor" else 1.0
+                    k["sustained_peak"], k["slots_per_instr"] = VALU_SUSTAINED_GINST, round(slots, 3)
+                    k["frac_of_sustained"] = round(k["achieved"] * slots / VALU_SUSTAINED_GINST, 4)
             else:
                 k["bound"] = "hbm"
                 alg = {"pyramid": W * H + 4.0 * rep.pyramid_pixels * 2 * 6,           # every plane written + read once
@@ -399,6 +410,7 @@ def main():
                              "frac_of_measured_ceiling": round(bytes_alg / (ms_img * 1e-3) / 1e9 / HBM_MEASURED_GBPS, 4),
                              # vector instructions of all kernels of an image (counter passes) over the timed rate
                              "valu_issue_frac": round(valu_img / (ms_img * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if valu_img else None,
+                             "valu_issue_frac_of_sustained": round(valu_img / (ms_img * 1e-3) / 1e9 / VALU_SUSTAINED_GINST, 4) if valu_img else None,
                              "hbm_traffic_frac": round(traffic / (ms_img * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None},
             "counters": "profiles/r04_kernel_counters.json" if not stale else None, "counters_stale": stale,
             "dominant": max(kernels, key=lambda k: k["ms"])["stage"], "kernels": kernels,

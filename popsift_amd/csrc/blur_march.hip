@@ -307,18 +307,21 @@ __global__ MARCH_BOUNDS void k_blur_march(BlurArgs a, BatchDesc bd)
 
 }  // namespace
 
-/* rows per segment (a multiple of 32) so that a launch over nb images has at least ~3 workgroups per CU, and at least
- * 64 rows (two steps) where the plane allows */
+/* Rows per segment (a multiple of 32): segments of EQUAL length, about MARCH_SEG_ROWS rows (seven steps) each, more and shorter
+ * ones where a launch over nb images would otherwise have fewer than want_wgs workgroups, never less than two steps where the
+ * plane allows.  Sixteen 3840 x 2160 planes per launch, summed time of the level launches of an image's octaves 0 and 1
+ * (tools/r04_seg_sweep.sh, one context): 160 / 224 / 288 / 384 / 448 / 544 / 736 / 1088 rows -> 83.6 / 84.4 / 86.9 / 89.3 /
+ * 88.2 / 88.8 / 94.6 / 102.4 us; the first version of this function took the LONGEST segment that gave want_wgs workgroups
+ * and left the remainder as the last one -- 2144 + 16 rows at sixteen planes, 704 + 704 + 704 + 48 at eight: 129.1 us. */
+constexpr int MARCH_SEG_ROWS = 224;
 int blur_march_seg_rows(int w, int h, int nb, int want_wgs)
 {
-    const int strips = (w + TW - 1) / TW;
-    int       best = ((h + MCH - 1) / MCH) * MCH;
-    for (int rows = best; rows >= 2 * MCH; rows -= MCH) {
-        const long wgs = (long)strips * ((h + rows - 1) / rows) * nb;
-        best = rows;
-        if (wgs >= want_wgs) break;
-    }
-    return best;
+    const int  strips = (w + TW - 1) / TW;
+    const long per_seg = (long)strips * std::max(nb, 1);
+    int        nseg = std::max((h + MARCH_SEG_ROWS - 1) / MARCH_SEG_ROWS, (int)((want_wgs + per_seg - 1) / per_seg));
+    nseg = std::max(1, std::min(nseg, std::max(h / (2 * MCH), 1)));
+    const int rows = ((h + nseg - 1) / nseg + MCH - 1) / MCH * MCH;
+    return std::max(rows, MCH);
 }
 
 bool blur_march_supported(const BlurArgs& a, int halo) { return a.dog_off < 0 && halo >= 0 && halo <= 16; }

@@ -672,8 +672,8 @@ hipError_t launch_blur(const BlurArgs& a, const BatchDesc& bd, int nb, int mode,
     const int halo = span - 1;
     if (halo < 0 || halo > 30) return hipErrorInvalidValue;
     /* Batches of large planes: the march kernel (blur_march.hip).  It pays where a workgroup makes many steps and the launch
-     * still fills the device -- several images per launch (a batch of eight 1080p planes: 17 steps per workgroup, 960
-     * workgroups: 17-21 us per plane against 17-26).  A SINGLE plane has no such operating point (3840 x 2160: 18-27 us
+     * still fills the device -- several images per launch (a batch of sixteen 1080p planes: 224-row segments, 4800
+     * workgroups of seven steps: 13-19 us per plane against 17-26).  A SINGLE plane has no such operating point (3840 x 2160: 18-27 us
      * against 17-26; 7680 x 4320: config 3's image 2.83-2.86 ms against 2.76 with the tile kernels): DESIGN 6.2. */
     if (mode == 0 && tune.path != 1 && blur_march_supported(a, halo)) {
         const long px = (long)a.w * a.h * nb;

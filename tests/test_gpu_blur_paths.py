@@ -93,7 +93,7 @@ def test_march_in_a_batch(gpu_hip):
 
 def test_the_batch_path_of_the_timed_loop_at_full_size(gpu_hip):
     """Four 1080p images in one submit: 4 x 8.3 Mpx per level launch of octave 0, so launch_blur takes the march kernels by
-    itself (no debug switch: the path of bench.py's timed loop, 544-row segments) -- every image equals its own single
+    itself (no debug switch: the path of bench.py's timed loop, equal segments of 224 rows) -- every image equals its own single
     submit, which the tile kernels build (features, orientations, descriptors and two planes bit for bit)."""
     imgs = [synth(100 + k, 1920, 1080) for k in range(4)]
     want, planes = [], []

@@ -440,6 +440,25 @@ def main():
                 "frac": round(big_bytes / (big_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "all_blur_launches": {"launches": all_n, "avg_launch_us": round(all_ms * 1e3 / max(all_n, 1), 2),
                                       "achieved": round(all_bytes / (all_ms * 1e-3) / 1e9, 1) if all_ms > 0 else 0.0}}
+        # ... and in a launch of the timed loop's size (the strip-march kernels, blur_march.hip): per PLANE
+        LBp = max(1, min(args.launch_batch, len(ptrs)))
+        if big_n and LBp > 1:
+            c0.set_profile(1)
+            b_ms = b_bytes = 0.0
+            b_n = 0
+            for _ in range(3):
+                c0.submit_batch_dev([ptrs[k % len(ptrs)] for k in range(LBp)], W, H, W)
+                c0.wait_batch()
+                r = c0.report()
+                b_ms += r.ms_big
+                b_bytes += r.big_alg_bytes
+                b_n += r.big_launches
+            c0.set_profile(0)
+            if b_n and b_ms > 0:
+                roofline["blur_level_launch"]["in_a_batch"] = {
+                    "kernel": "k_blur_march<HALO> (the same level, %d images per launch)" % LBp, "launches": b_n,
+                    "avg_us_per_plane": round(b_ms * 1e3 / b_n / LBp, 2), "achieved": round(b_bytes / (b_ms * 1e-3) / 1e9, 1),
+                    "frac": round(b_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         leg("blur_profile")
         # ---- a keypoint-sparse image: the pyramid-bound regime ------------------------------------------------------
         if not args.only_roofline:
